@@ -1,0 +1,233 @@
+/*
+ * hip_executor.h — C ABI of the MI355X (gfx950) tracing executor.
+ *
+ * This library replaces the reference's OpenCL back end (class OpenClExecutor,
+ * opencl_executor.h:12-95 / opencl_executor.cpp:8-524) and the device-facing half of its
+ * render driver (ray_tracer_cl.cpp:9-262).  Everything here is plain C: opaque handle,
+ * pointers, sizes and PODs, so it can be bound from C++ (ray_tracer_hip.cpp), ctypes or
+ * any other FFI.  Every function returns 0 on success and a negative HIPEXEC_E_* code on
+ * failure and never throws; hipexec_last_error() returns the message for the calling
+ * thread's last failure.
+ *
+ * Arithmetic contract: all tracing arithmetic is IEEE-754 binary32, evaluated in the
+ * reference's source order with no FMA contraction, correctly rounded divide and sqrt.
+ * Two rule sets exist because the reference's two back ends disagree:
+ *   HIPEXEC_MODE_CPU  follows ray_tracer.cpp (4 samples per pixel, ambient term, inclusive
+ *                     barycentric edges, 1e-4 thresholds, sphere wins ties, optional
+ *                     recursive reflection);
+ *   HIPEXEC_MODE_CL   follows ray_tracer_cl.cpp + cl_kernels.c (1 sample per pixel, no
+ *                     ambient, strict edges, 1e-3 thresholds, triangle wins ties, no
+ *                     reflection).
+ */
+#ifndef HIP_EXECUTOR_H
+#define HIP_EXECUTOR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPEXEC_MODE_CPU 0
+#define HIPEXEC_MODE_CL  1
+
+#define HIPEXEC_OK            0
+#define HIPEXEC_E_INVALID    -1   /* bad argument (null pointer, negative size, bad index) */
+#define HIPEXEC_E_DEVICE     -2   /* a HIP runtime call failed                               */
+#define HIPEXEC_E_NOMEM      -3   /* host or device allocation failed                        */
+#define HIPEXEC_E_LIMIT      -4   /* input exceeds a documented limit                        */
+
+/* Rows of a frame are grouped in tiles of HIPEXEC_TILE_ROWS scanlines; a tile is the unit
+ * of multi-GPU sharding (tile k of the frame covers rows [8k, 8k+8)). */
+#define HIPEXEC_TILE_ROWS 8
+
+typedef struct hipexec hipexec_t;
+
+/*
+ * Flattened scene.  Replaces the pointer-chasing `Scene` of scene.h:143-153 at the boundary;
+ * values are exactly what scene.cpp:15-135 leaves in the Scene (triangle edges already
+ * relative to p, UVs already in texel units, sphere centres and lamp positions already
+ * truncated to integers).  All arrays are caller-owned and only read during
+ * hipexec_create().  A material index of -1 means "no material" and behaves like the
+ * default Material() of scene.h:32-44 (black, all factors 0, untextured).
+ */
+typedef struct hipexec_scene_desc {
+    /* triangles: scene.h:100-120 */
+    uint32_t       n_tri;
+    const float   *tri_p;      /* [n_tri][3]  first vertex                                  */
+    const float   *tri_e1;     /* [n_tri][3]  v1 - v0                                       */
+    const float   *tri_e2;     /* [n_tri][3]  v2 - v0                                       */
+    const float   *tri_norm;   /* [n_tri][3]  normalize(cross(e1,e2)) as stored by the loader */
+    const float   *tri_uv;     /* [n_tri][6]  uvStart.xy, uvU.xy, uvV.xy (texel units); may be NULL */
+    const int32_t *tri_mat;    /* [n_tri]     material index or -1                          */
+    /* spheres: scene.h:123-131 */
+    uint32_t       n_sph;
+    const float   *sph_center; /* [n_sph][3]                                                */
+    const float   *sph_radius; /* [n_sph]                                                   */
+    const int32_t *sph_mat;    /* [n_sph]                                                   */
+    /* materials: scene.h:21-45 */
+    uint32_t       n_mat;
+    const float   *mat_color;  /* [n_mat][3]  diffusiveColor                                */
+    const float   *mat_kd;     /* [n_mat]     diffusiveFactor                               */
+    const float   *mat_ks;     /* [n_mat]     specularFactor                                */
+    const float   *mat_hard;   /* [n_mat]     specularHardness                              */
+    const float   *mat_kr;     /* [n_mat]     reflectionFactor                              */
+    const int32_t *mat_tex;    /* [n_mat]     texture index or -1 (Material::textured)      */
+    /* textures: tex_image.h:13-69, decoded RGBA8 rows top-down as LodePNG leaves them */
+    uint32_t       n_tex;
+    const uint8_t *tex_rgba;   /* all textures back to back                                 */
+    const uint64_t*tex_offset; /* [n_tex]  byte offset of each texture in tex_rgba          */
+    const uint32_t*tex_w;      /* [n_tex]                                                   */
+    const uint32_t*tex_h;      /* [n_tex]                                                   */
+    /* lamps: scene.h:134-140 */
+    uint32_t       n_lamp;
+    const float   *lamp_pos;        /* [n_lamp][3]                                          */
+    const float   *lamp_intensity;  /* [n_lamp]                                             */
+    const float   *lamp_distance;   /* [n_lamp]                                             */
+    /* camera and world: scene.h:148-152 */
+    float cam_pos[3];
+    float cam_mat[9];          /* cam_mat[3*i+c] = JSON transform[i][c]; world[i] = sum_c cam_mat[3*i+c]*cam[c] */
+    float horizon[3];          /* worldHorizonColor                                         */
+    float ambient[3];          /* worldAmbientColor                                         */
+} hipexec_scene_desc;
+
+/* Run-time counterpart of the compile-time knobs of config.h:8-20. */
+typedef struct hipexec_render_cfg {
+    int32_t width;        /* full frame width  (WIDTH)                                      */
+    int32_t height;       /* full frame height (HEIGHT)                                     */
+    int32_t mode;         /* HIPEXEC_MODE_CPU or HIPEXEC_MODE_CL                            */
+    int32_t max_depth;    /* MAX_REFLECTION_DEPTH with ENABLE_REFLECTION; 0 = reflection off.
+                             Ignored (treated as 0) in HIPEXEC_MODE_CL.                     */
+    int32_t tone;         /* 1: store powf(c/2.2f, 0.3f) per channel (ray_tracer.cpp:47-51);
+                             0: store the linear colour                                     */
+    int32_t tile_first;   /* first 8-row tile rendered by this call                          */
+    int32_t tile_step;    /* stride between rendered tiles (1 = whole frame; G = one of G
+                             interleaved shards)                                            */
+    int32_t flags;        /* bit 0: time every kernel with HIP events (fills *_ms in stats)  */
+} hipexec_render_cfg;
+
+#define HIPEXEC_FLAG_TIME_KERNELS 1
+
+/* Kernel classes reported in hipexec_stats. */
+enum {
+    HIPEXEC_K_PRIMARY = 0,   /* closest hit of camera rays (hoisted per-triangle constants)  */
+    HIPEXEC_K_CLOSEST = 1,   /* closest hit of bounce / user rays                            */
+    HIPEXEC_K_ANYHIT  = 2,   /* shadow rays                                                  */
+    HIPEXEC_K_SHADE   = 3,   /* shadow-ray generation, shading, resolve, packing             */
+    HIPEXEC_K_COUNT   = 4
+};
+
+/*
+ * Work counters of one call.  A "ray" is one closest-hit or any-hit query.  tests_* is the
+ * algorithmic number of ray-primitive tests of the reference's linear scans: n_tri + n_sph
+ * per closest-hit ray; (index of the first occluder in scan order) + 1, or n_tri + n_sph
+ * when unoccluded, per shadow ray.
+ */
+typedef struct hipexec_stats {
+    uint64_t rays_primary;
+    uint64_t rays_bounce;
+    uint64_t rays_shadow;
+    uint64_t tests_tri_closest;   /* ray-triangle tests of primary + bounce rays            */
+    uint64_t tests_sph_closest;
+    uint64_t tests_tri_any;       /* ray-triangle tests of shadow rays (reference order)    */
+    uint64_t tests_sph_any;
+    uint64_t tests_tri_primary;   /* part of tests_tri_closest due to primary rays          */
+    uint32_t launches[HIPEXEC_K_COUNT];
+    float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */
+    float    total_ms;                     /* HIP-event time of the whole call on its stream */
+} hipexec_stats;
+
+/* One closest-hit result: the `Hit` of scene.h:48-63 plus the identifiers the reference
+ * keeps only implicitly (object index, barycentrics). */
+typedef struct hipexec_hit {
+    int32_t id;        /* -1 miss; [0,n_tri) triangle index; n_tri + k sphere k             */
+    int32_t mat;       /* material index of the hit object or -1                            */
+    float   t, u, v;   /* u,v are 0 for spheres and misses                                  */
+    float   point[3];
+    float   norm[3];
+    float   color[3];  /* material colour, or texel-blended colour for textured triangles   */
+} hipexec_hit;
+
+/*
+ * Replaces OpenClExecutor::OpenClExecutor (opencl_executor.cpp:8-108): selects a device,
+ * flattens and uploads the scene once.  `device` is a HIP device ordinal (-1: current).
+ */
+int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device);
+
+/* Replaces OpenClExecutor::~OpenClExecutor (opencl_executor.cpp:110-147). NULL is a no-op. */
+void hipexec_destroy(hipexec_t *h);
+
+/*
+ * Use `stream` (a hipStream_t) for all work of later calls instead of the executor's own
+ * stream; NULL restores the own stream.  No counterpart in the reference (its queue is
+ * private, opencl_executor.cpp:37-41); exists so a caller can order the work with its own
+ * HIP work (e.g. an RCCL gather) without a device-wide synchronisation.
+ */
+int hipexec_set_stream(hipexec_t *h, void *stream);
+
+/*
+ * Replaces renderSceneCl (ray_tracer_cl.cpp:9-56, HIPEXEC_MODE_CL) and renderScene
+ * (ray_tracer.cpp:7-54, HIPEXEC_MODE_CPU): renders the tiles selected by cfg into host
+ * memory and returns when the pixels are there.
+ *   out_rgb : [height][width][3] floats, the image_bitmap layout (image_bitmap.h:22,45),
+ *             row 0 first; rows of tiles this call does not render are left untouched.
+ *   out_ids : optional [height][width][spp] hit identifiers of the primary samples
+ *             (spp = 4 in HIPEXEC_MODE_CPU, 1 in HIPEXEC_MODE_CL), encoding of hipexec_hit.id.
+ *   stats   : optional.
+ */
+int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg,
+                   float *out_rgb, int32_t *out_ids, hipexec_stats *stats);
+
+/*
+ * Same work as hipexec_render but asynchronous and device-resident: results stay in device
+ * memory of the executor's device, for a caller that gathers shards itself.
+ *   d_out_rgba : device pointer, [n_tiles*8][width][4] floats (RGB + 1.0), the rendered
+ *                tiles back to back in increasing tile order.
+ *   d_out_ids  : optional device pointer, [n_tiles*8][width][spp] int32.
+ * n_tiles = number of k >= 0 with tile_first + k*tile_step < ceil(height/8).
+ * The call enqueues on the executor's stream and returns; stats (optional, host memory) are
+ * complete only after hipexec_sync().
+ */
+int hipexec_render_device(hipexec_t *h, const hipexec_render_cfg *cfg,
+                          float *d_out_rgba, int32_t *d_out_ids, hipexec_stats *stats);
+
+/* Blocks until all work enqueued by this executor has finished and pending stats are final. */
+int hipexec_sync(hipexec_t *h);
+
+/*
+ * Replaces computeClosestHitsCl (ray_tracer_cl.cpp:181-242) and with it
+ * OpenClExecutor::computeClosestHitTriangle / computeClosestHitSphere
+ * (opencl_executor.cpp:149-264, 341-449): closest hit, triangle/sphere merge, material and
+ * texture lookup for a batch of rays.  rays6 is host memory, n rays of {p_x,p_y,p_z,d_x,d_y,d_z}
+ * (the RayData packing of scene.h:156-169).  n = 0 is legal.
+ */
+int hipexec_closest_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n,
+                         hipexec_hit *out);
+
+/*
+ * Replaces computeAnyHitsCl (ray_tracer_cl.cpp:245-262) and OpenClExecutor::computeAnyHitTriangle /
+ * computeAnyHitSphere (opencl_executor.cpp:266-339, 451-524).  hits[i] is OR-ed with the
+ * occlusion result like the reference does (caller pre-initialises).
+ */
+int hipexec_any_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, char *hits);
+
+/*
+ * Replaces traceRaysCl (ray_tracer_cl.cpp:108-178, HIPEXEC_MODE_CL) / traceRay
+ * (ray_tracer.cpp:156-201, HIPEXEC_MODE_CPU) for a batch of rays: colours3[i] ([n][3]
+ * floats, host) is accumulated into (+=) as the reference does, caller pre-zeros.
+ * max_depth as in hipexec_render_cfg.
+ */
+int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6, uint32_t n,
+                       float *colours3, hipexec_stats *stats);
+
+/* Message of the calling thread's last failed call ("" if none).  Mirrors the reference's
+ * diagnostics on std::cerr (opencl_executor.h:67-72) without printing. */
+const char *hipexec_last_error(void);
+
+/* Library ABI version; bumped when a struct layout changes. */
+int hipexec_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_EXECUTOR_H */

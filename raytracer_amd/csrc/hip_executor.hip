@@ -1,0 +1,660 @@
+// hip_executor.hip — host side of the C ABI declared in include/hip_executor.h.
+//
+// Owns the device copy of the scene, the ray/hit/colour work buffers and the per-frame
+// sequence of kernel launches.  Build with -ffp-contract=off (see rt_device.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "hip_executor.h"
+#include "rt_kernels.hpp"
+
+using namespace rt;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? HIPEXEC_E_NOMEM : HIPEXEC_E_DEVICE,          \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define CHK(expr) do { int r_ = (expr); if (r_ != HIPEXEC_OK) return r_; } while (0)
+
+// grow-only device buffer
+struct Buf {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return HIPEXEC_OK;
+        if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return HIPEXEC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct TimedLaunch { hipEvent_t a, b; int klass; };
+
+constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte shadow rays per batch
+constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk of the batch entry points
+
+}  // namespace
+
+struct hipexec {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DScene S{};
+    uint32_t lamp_words = 1;
+    std::vector<void *> scene_allocs;
+    Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
+    uint32_t *d_cnt32 = nullptr;              // [0] shadow queue fill, [1] next-level queue fill
+    unsigned long long *d_cnt64 = nullptr;    // [0] any-hit triangle tests, [1] any-hit sphere tests
+    uint32_t *h_cnt32 = nullptr;              // pinned
+    unsigned long long *h_cnt64 = nullptr;    // pinned
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    bool timing = false;
+    hipexec_stats *pending_stats = nullptr;
+    hipexec_stats acc{};
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool call_open = false;
+};
+
+namespace {
+
+template <class T>
+int upload(hipexec *h, const T *src, size_t count, T **dst, size_t min_count = 1)
+{
+    size_t n = std::max(count, min_count);
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, n * sizeof(T)));
+    h->scene_allocs.push_back(p);
+    HIPCHK(hipMemset(p, 0, n * sizeof(T)));
+    if (count && src) HIPCHK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<T *>(p);
+    return HIPEXEC_OK;
+}
+
+int validate_scene(const hipexec_scene_desc *s)
+{
+    if (!s) return fail(HIPEXEC_E_INVALID, "scene descriptor is NULL");
+    if (s->n_tri && (!s->tri_p || !s->tri_e1 || !s->tri_e2 || !s->tri_norm))
+        return fail(HIPEXEC_E_INVALID, "triangle arrays missing");
+    if (s->n_sph && (!s->sph_center || !s->sph_radius)) return fail(HIPEXEC_E_INVALID, "sphere arrays missing");
+    if (s->n_mat && (!s->mat_color || !s->mat_kd || !s->mat_ks || !s->mat_hard || !s->mat_kr))
+        return fail(HIPEXEC_E_INVALID, "material arrays missing");
+    if (s->n_lamp && (!s->lamp_pos || !s->lamp_intensity || !s->lamp_distance))
+        return fail(HIPEXEC_E_INVALID, "lamp arrays missing");
+    if (s->n_tex && (!s->tex_rgba || !s->tex_offset || !s->tex_w || !s->tex_h))
+        return fail(HIPEXEC_E_INVALID, "texture arrays missing");
+    if (s->n_tri > 0x7ff00000u || s->n_sph > 0x00100000u) return fail(HIPEXEC_E_LIMIT, "too many primitives");
+    for (uint32_t i = 0; i < s->n_tri && s->tri_mat; i++)
+        if (s->tri_mat[i] < -1 || s->tri_mat[i] >= (int32_t)s->n_mat)
+            return fail(HIPEXEC_E_INVALID, "triangle %u: material index %d out of range", i, s->tri_mat[i]);
+    for (uint32_t i = 0; i < s->n_sph && s->sph_mat; i++)
+        if (s->sph_mat[i] < -1 || s->sph_mat[i] >= (int32_t)s->n_mat)
+            return fail(HIPEXEC_E_INVALID, "sphere %u: material index %d out of range", i, s->sph_mat[i]);
+    for (uint32_t i = 0; i < s->n_mat && s->mat_tex; i++)
+        if (s->mat_tex[i] < -1 || s->mat_tex[i] >= (int32_t)s->n_tex)
+            return fail(HIPEXEC_E_INVALID, "material %u: texture index %d out of range", i, s->mat_tex[i]);
+    return HIPEXEC_OK;
+}
+
+int build_scene(hipexec *h, const hipexec_scene_desc *s)
+{
+    DScene &S = h->S;
+    S.n_tri = s->n_tri; S.n_sph = s->n_sph; S.n_lamp = s->n_lamp; S.n_mat = s->n_mat;
+    S.n_tri_pad = (s->n_tri + TRI_PAD - 1) / TRI_PAD * TRI_PAD;
+    if (S.n_tri_pad == 0) S.n_tri_pad = 0;
+    h->lamp_words = std::max(1u, (s->n_lamp + 31u) / 32u);
+    memcpy(S.cam_pos, s->cam_pos, sizeof S.cam_pos); memcpy(S.cam_mat, s->cam_mat, sizeof S.cam_mat);
+    memcpy(S.horizon, s->horizon, sizeof S.horizon); memcpy(S.ambient, s->ambient, sizeof S.ambient);
+
+    // centre of the scene's bounding box: origin of the FILTER coordinates
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    auto grow = [&](double x, double y, double z) {
+        double v[3] = {x, y, z};
+        for (int k = 0; k < 3; k++) if (std::isfinite(v[k])) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); }
+    };
+    for (uint32_t i = 0; i < s->n_tri; i++) {
+        const float *p = s->tri_p + 3 * (size_t)i, *a = s->tri_e1 + 3 * (size_t)i, *b = s->tri_e2 + 3 * (size_t)i;
+        grow(p[0], p[1], p[2]); grow(p[0] + a[0], p[1] + a[1], p[2] + a[2]); grow(p[0] + b[0], p[1] + b[1], p[2] + b[2]);
+    }
+    for (uint32_t i = 0; i < s->n_sph; i++) grow(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2]);
+    for (int k = 0; k < 3; k++) S.center[k] = (lo[k] <= hi[k]) ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
+
+    // triangles
+    float *d_p = nullptr, *d_e1 = nullptr, *d_e2 = nullptr;
+    CHK(upload(h, s->tri_p, 3 * (size_t)s->n_tri, &d_p));
+    CHK(upload(h, s->tri_e1, 3 * (size_t)s->n_tri, &d_e1));
+    CHK(upload(h, s->tri_e2, 3 * (size_t)s->n_tri, &d_e2));
+    float4 *ex = nullptr, *px = nullptr, *fp = nullptr, *fg = nullptr;
+    CHK(upload<float4>(h, nullptr, 0, &ex, 3 * (size_t)S.n_tri_pad + 1));
+    CHK(upload<float4>(h, nullptr, 0, &px, 3 * (size_t)S.n_tri_pad + 1));
+    CHK(upload<float4>(h, nullptr, 0, &fp, 3 * (size_t)S.n_tri_pad + 1));
+    CHK(upload<float4>(h, nullptr, 0, &fg, 5 * (size_t)S.n_tri_pad + 1));
+    if (S.n_tri_pad) {
+        f3 cam = {S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]}, cen = {S.center[0], S.center[1], S.center[2]};
+        hipLaunchKernelGGL(k_setup_triangles, dim3((S.n_tri_pad + 255) / 256), dim3(256), 0, h->stream,
+                           S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, cam, cen, ex, px, fp, fg);
+        HIPCHK(hipGetLastError());
+    }
+    S.tri_exact = ex; S.tri_primx = px; S.tri_fastp = fp; S.tri_fastg = fg;
+    float *d_norm = nullptr, *d_uv = nullptr; int *d_tmat = nullptr;
+    CHK(upload(h, s->tri_norm, 3 * (size_t)s->n_tri, &d_norm));
+    CHK(upload(h, s->tri_uv, s->tri_uv ? 6 * (size_t)s->n_tri : 0, &d_uv, 6 * (size_t)std::max(1u, s->n_tri)));
+    std::vector<int> tmat(std::max(1u, s->n_tri), (int)s->n_mat);
+    for (uint32_t i = 0; i < s->n_tri; i++) tmat[i] = (s->tri_mat && s->tri_mat[i] >= 0) ? s->tri_mat[i] : (int)s->n_mat;
+    CHK(upload(h, tmat.data(), tmat.size(), &d_tmat));
+    S.tri_norm = d_norm; S.tri_uv = d_uv; S.tri_mat = d_tmat;
+
+    // spheres
+    std::vector<float4> sph(std::max(1u, s->n_sph));
+    std::vector<int> smat(std::max(1u, s->n_sph), (int)s->n_mat);
+    for (uint32_t i = 0; i < s->n_sph; i++) {
+        sph[i] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
+        smat[i] = (s->sph_mat && s->sph_mat[i] >= 0) ? s->sph_mat[i] : (int)s->n_mat;
+    }
+    float4 *d_sph = nullptr; int *d_smat = nullptr;
+    CHK(upload(h, sph.data(), sph.size(), &d_sph)); CHK(upload(h, smat.data(), smat.size(), &d_smat));
+    S.sph = d_sph; S.sph_mat = d_smat;
+
+    // materials; entry n_mat is the default Material() of scene.h:32-44
+    std::vector<float4> ma(s->n_mat + 1), mb(s->n_mat + 1);
+    for (uint32_t i = 0; i < s->n_mat; i++) {
+        ma[i] = make_float4(s->mat_color[3 * i], s->mat_color[3 * i + 1], s->mat_color[3 * i + 2], s->mat_kd[i]);
+        int tex = s->mat_tex ? s->mat_tex[i] : -1;
+        float texf; memcpy(&texf, &tex, 4);
+        mb[i] = make_float4(s->mat_ks[i], s->mat_hard[i], s->mat_kr[i], texf);
+    }
+    { int tex = -1; float texf; memcpy(&texf, &tex, 4);
+      ma[s->n_mat] = make_float4(0.f, 0.f, 0.f, 0.f); mb[s->n_mat] = make_float4(0.f, 0.f, 0.f, texf); }
+    float4 *d_ma = nullptr, *d_mb = nullptr;
+    CHK(upload(h, ma.data(), ma.size(), &d_ma)); CHK(upload(h, mb.data(), mb.size(), &d_mb));
+    S.mat_a = d_ma; S.mat_b = d_mb;
+
+    // textures
+    uint64_t tex_bytes = 0;
+    for (uint32_t i = 0; i < s->n_tex; i++) tex_bytes = std::max<uint64_t>(tex_bytes, s->tex_offset[i] + (uint64_t)s->tex_w[i] * s->tex_h[i] * 4);
+    uint8_t *d_tex = nullptr; uint64_t *d_toff = nullptr; uint32_t *d_tw = nullptr, *d_th = nullptr;
+    CHK(upload(h, s->tex_rgba, (size_t)tex_bytes, &d_tex, 16));
+    CHK(upload(h, s->tex_offset, s->n_tex, &d_toff)); CHK(upload(h, s->tex_w, s->n_tex, &d_tw)); CHK(upload(h, s->tex_h, s->n_tex, &d_th));
+    S.tex = d_tex; S.tex_off = d_toff; S.tex_w = d_tw; S.tex_h = d_th;
+
+    // lamps
+    std::vector<float4> lamp(std::max(1u, s->n_lamp));
+    for (uint32_t i = 0; i < s->n_lamp; i++)
+        lamp[i] = make_float4(s->lamp_pos[3 * i], s->lamp_pos[3 * i + 1], s->lamp_pos[3 * i + 2], s->lamp_intensity[i]);
+    float4 *d_lamp = nullptr; float *d_ld = nullptr;
+    CHK(upload(h, lamp.data(), lamp.size(), &d_lamp)); CHK(upload(h, s->lamp_distance, s->n_lamp, &d_ld));
+    S.lamp = d_lamp; S.lamp_dist = d_ld;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HIPEXEC_OK;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------
+int timed_begin(hipexec *h, int klass)
+{
+    h->acc.launches[klass]++;
+    if (!h->timing) return HIPEXEC_OK;
+    TimedLaunch t; t.klass = klass;
+    for (hipEvent_t *e : {&t.a, &t.b}) {
+        if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
+        else HIPCHK(hipEventCreate(e));
+    }
+    HIPCHK(hipEventRecord(t.a, h->stream));
+    h->timed.push_back(t);
+    return HIPEXEC_OK;
+}
+int timed_end(hipexec *h)
+{
+    HIPCHK(hipGetLastError());
+    if (!h->timing) return HIPEXEC_OK;
+    HIPCHK(hipEventRecord(h->timed.back().b, h->stream));
+    return HIPEXEC_OK;
+}
+#define LAUNCH(klass, kernel, grid, ...)                                                       \
+    do {                                                                                       \
+        CHK(timed_begin(h, klass));                                                            \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, h->stream, __VA_ARGS__);          \
+        CHK(timed_end(h));                                                                     \
+    } while (0)
+
+inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
+
+int call_begin(hipexec *h, bool timing)
+{
+    HIPCHK(hipSetDevice(h->device));
+    if (h->call_open) {   // a previous asynchronous call has not been collected yet
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->timing = timing;
+    memset(&h->acc, 0, sizeof h->acc);
+    h->call_open = true;
+    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+    return HIPEXEC_OK;
+}
+
+// finish a call: wait, collect timings and counters into *stats (optional)
+int call_end(hipexec *h, hipexec_stats *stats)
+{
+    HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->acc.tests_tri_any = h->h_cnt64[0];
+    h->acc.tests_sph_any = h->h_cnt64[1];
+    HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
+    for (TimedLaunch &t : h->timed) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, t.a, t.b));
+        h->acc.kernel_ms[t.klass] += ms;
+        h->event_pool.push_back(t.a); h->event_pool.push_back(t.b);
+    }
+    h->timed.clear();
+    h->call_open = false;
+    if (stats) *stats = h->acc;
+    return HIPEXEC_OK;
+}
+
+int read_count(hipexec *h, int which, uint32_t *out)
+{
+    HIPCHK(hipMemcpyAsync(h->h_cnt32 + which, h->d_cnt32 + which, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = h->h_cnt32[which];
+    return HIPEXEC_OK;
+}
+
+template <int MODE>
+int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
+{
+    constexpr int R = 2;
+    uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
+    LAUNCH(HIPEXEC_K_CLOSEST, (k_closest<MODE, R, true>), blocks_for(waves * 64), h->S, rays, n, hits);
+    return HIPEXEC_OK;
+}
+
+// Shadow rays, shading and bounces for n0 level-0 rays whose records are in rayA and whose
+// closest hits are in hit0.  Leaves per-level colours in h->local ([level][stride]).
+template <int MODE>
+int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *levels_used)
+{
+    const DScene &S = h->S;
+    float4 *cur_rays = h->rayA.as<float4>(), *next_rays = h->rayB.as<float4>();
+    float4 *cur_hits = h->hit0.as<float4>();
+    uint32_t n = n0;
+    int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : std::max(0, max_depth);
+    int level = 0;
+    for (;; level++) {
+        if (S.n_lamp) {
+            HIPCHK(hipMemsetAsync(h->d_cnt32, 0, 2 * sizeof(uint32_t), h->stream));
+            LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
+                   h->shadowq.as<float4>(), h->d_cnt32);
+            uint32_t nsh = 0;
+            CHK(read_count(h, 0, &nsh));
+            h->acc.rays_shadow += nsh;
+            if (nsh)
+                LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<MODE, true>), blocks_for(nsh), S, h->shadowq.as<float4>(), nsh,
+                       h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64);
+        } else {
+            HIPCHK(hipMemsetAsync(h->d_cnt32, 0, 2 * sizeof(uint32_t), h->stream));
+        }
+        bool spawn = level < depth;
+        LAUNCH(HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
+               h->lamp_words, h->local.as<float4>() + (size_t)level * stride, spawn, next_rays, h->d_cnt32 + 1);
+        if (!spawn) break;
+        uint32_t nn = 0;
+        CHK(read_count(h, 1, &nn));
+        if (nn == 0) break;
+        h->acc.rays_bounce += nn;
+        h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
+        h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
+        CHK(launch_closest<MODE>(h, next_rays, nn, h->hitN.as<float4>()));
+        std::swap(cur_rays, next_rays);
+        cur_hits = h->hitN.as<float4>();
+        n = nn;
+    }
+    *levels_used = level + 1;
+    return HIPEXEC_OK;
+}
+
+int reserve_trace_buffers(hipexec *h, uint64_t n0, int levels)
+{
+    CHK(h->rayA.reserve(n0 * 32)); CHK(h->rayB.reserve(n0 * 32));
+    CHK(h->hit0.reserve(n0 * 16)); CHK(h->hitN.reserve(n0 * 16));
+    CHK(h->local.reserve(n0 * 16 * (uint64_t)levels));
+    size_t occl_bytes = n0 * 4 * h->lamp_words;
+    if (occl_bytes > h->occl.cap) {
+        CHK(h->occl.reserve(occl_bytes));
+        HIPCHK(hipMemsetAsync(h->occl.p, 0, h->occl.cap, h->stream));
+    }
+    CHK(h->shadowq.reserve(std::max<uint64_t>(1, n0 * h->S.n_lamp) * 32));
+    return HIPEXEC_OK;
+}
+
+int n_tiles_of(const hipexec_render_cfg *c)
+{
+    int total = (c->height + HIPEXEC_TILE_ROWS - 1) / HIPEXEC_TILE_ROWS;
+    if (c->tile_first >= total) return 0;
+    return (total - c->tile_first + c->tile_step - 1) / c->tile_step;
+}
+
+int validate_cfg(const hipexec_render_cfg *c)
+{
+    if (!c) return fail(HIPEXEC_E_INVALID, "render cfg is NULL");
+    if (c->width <= 0 || c->height <= 0) return fail(HIPEXEC_E_INVALID, "frame size %dx%d is not positive", c->width, c->height);
+    if (c->width > 65536 || c->height > 65536) return fail(HIPEXEC_E_LIMIT, "frame size %dx%d exceeds 65536", c->width, c->height);
+    if (c->mode != HIPEXEC_MODE_CPU && c->mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", c->mode);
+    if (c->max_depth < 0 || c->max_depth > 64) return fail(HIPEXEC_E_LIMIT, "max_depth %d outside [0,64]", c->max_depth);
+    if (c->tile_first < 0 || c->tile_step < 1) return fail(HIPEXEC_E_INVALID, "bad tile selection %d/%d", c->tile_first, c->tile_step);
+    return HIPEXEC_OK;
+}
+
+template <int MODE>
+int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
+{
+    constexpr int SPP = (MODE == HIPEXEC_MODE_CL) ? 1 : 4;
+    const DScene &S = h->S;
+    int n_tiles = n_tiles_of(c);
+    int nbx = (c->width + 7) / 8;
+    int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : c->max_depth;
+    // tiles per batch, bounded by the shadow queue
+    uint64_t samples_per_tile = (uint64_t)nbx * 64 * SPP;
+    uint64_t per_tile_entries = samples_per_tile * std::max(1u, S.n_lamp);
+    int tiles_per_batch = (int)std::max<uint64_t>(1, SHADOW_QUEUE_MAX_ENTRIES / per_tile_entries);
+    for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_batch) {
+        Frame F;
+        F.W = c->width; F.H = c->height; F.tile_step = c->tile_step;
+        F.tile_first = c->tile_first + t0 * c->tile_step;
+        F.n_tiles = std::min(tiles_per_batch, n_tiles - t0);
+        F.nbx = nbx; F.n_slots = (uint32_t)F.n_tiles * (uint32_t)nbx * 64u; F.spp = SPP;
+        uint64_t n0 = (uint64_t)F.n_slots * SPP;
+        if (n0 > 0xfffffff0ull) return fail(HIPEXEC_E_LIMIT, "batch of %llu samples exceeds 32-bit indexing", (unsigned long long)n0);
+        CHK(reserve_trace_buffers(h, n0, depth + 1));
+        LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE, true>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>());
+        int rows = std::min(F.n_tiles * HIPEXEC_TILE_ROWS, c->height - F.tile_first * HIPEXEC_TILE_ROWS);
+        if (c->tile_step != 1) {
+            rows = 0;
+            for (int k = 0; k < F.n_tiles; k++)
+                rows += std::max(0, std::min(HIPEXEC_TILE_ROWS, c->height - (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS));
+        }
+        uint64_t prim = (uint64_t)rows * c->width * SPP;
+        h->acc.rays_primary += prim;
+        h->acc.tests_tri_primary += prim * S.n_tri;
+        h->acc.tests_tri_closest += prim * S.n_tri;
+        h->acc.tests_sph_closest += prim * S.n_sph;
+        int levels_used = 1;
+        CHK(trace_levels<MODE>(h, (uint32_t)n0, (size_t)n0, depth, &levels_used));
+        size_t row0 = (size_t)t0 * HIPEXEC_TILE_ROWS;
+        LAUNCH(HIPEXEC_K_SHADE, (k_resolve<MODE>), blocks_for(F.n_slots), F, h->local.as<float4>(), (size_t)n0, levels_used,
+               h->hit0.as<float4>(), c->tone, d_rgba + row0 * c->width, d_ids ? d_ids + row0 * c->width * SPP : nullptr);
+    }
+    return HIPEXEC_OK;
+}
+
+int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
+{
+    if (c->mode == HIPEXEC_MODE_CL) return render_tiles<HIPEXEC_MODE_CL>(h, c, d_rgba, d_ids);
+    return render_tiles<HIPEXEC_MODE_CPU>(h, c, d_rgba, d_ids);
+}
+
+// rays6 (host) -> ray records in rayA, sample index = position
+__global__ void k_import_rays(const float *__restrict__ rays6, uint32_t n, float4 *__restrict__ recs)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays6 + 6 * (size_t)i;
+    store_ray(recs, i, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), i, 0u);
+}
+
+int import_rays(hipexec *h, const float *rays6, uint32_t n)
+{
+    CHK(h->stage_in.reserve((size_t)n * 24));
+    CHK(h->rayA.reserve((size_t)n * 32));
+    HIPCHK(hipMemcpyAsync(h->stage_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(HIPEXEC_K_SHADE, k_import_rays, blocks_for(n), h->stage_in.as<float>(), n, h->rayA.as<float4>());
+    return HIPEXEC_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int hipexec_abi_version(void) { return 1; }
+
+const char *hipexec_last_error(void) { return g_err; }
+
+int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
+{
+    if (!out) return fail(HIPEXEC_E_INVALID, "out handle pointer is NULL");
+    *out = nullptr;
+    CHK(validate_scene(scene));
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(HIPEXEC_E_DEVICE, "no HIP device available");
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    if (device >= count) return fail(HIPEXEC_E_INVALID, "device %d out of range (%d devices)", device, count);
+    HIPCHK(hipSetDevice(device));
+    hipexec *h = new (std::nothrow) hipexec();
+    if (!h) return fail(HIPEXEC_E_NOMEM, "out of host memory");
+    h->device = device;
+    int rc = [&]() -> int {
+        HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        h->stream = h->own_stream;
+        HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end));
+        HIPCHK(hipMalloc((void **)&h->d_cnt32, 8 * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&h->d_cnt64, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void **)&h->h_cnt32, 8 * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h->h_cnt64, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipMemset(h->d_cnt32, 0, 8 * sizeof(uint32_t)));
+        HIPCHK(hipMemset(h->d_cnt64, 0, 4 * sizeof(unsigned long long)));
+        return build_scene(h, scene);
+    }();
+    if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
+    *out = h;
+    return HIPEXEC_OK;
+}
+
+void hipexec_destroy(hipexec_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->scene_allocs) (void)hipFree(p);
+    for (Buf *b : {&h->rayA, &h->rayB, &h->hit0, &h->hitN, &h->local, &h->occl, &h->shadowq, &h->out_rgba, &h->out_ids,
+                   &h->stage_in, &h->stage_out}) b->release();
+    if (h->d_cnt32) (void)hipFree(h->d_cnt32);
+    if (h->d_cnt64) (void)hipFree(h->d_cnt64);
+    if (h->h_cnt32) (void)hipHostFree(h->h_cnt32);
+    if (h->h_cnt64) (void)hipHostFree(h->h_cnt64);
+    for (TimedLaunch &t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int hipexec_set_stream(hipexec_t *h, void *stream)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    return HIPEXEC_OK;
+}
+
+int hipexec_sync(hipexec_t *h)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->call_open) {
+        hipexec_stats *dst = h->pending_stats;
+        h->pending_stats = nullptr;
+        return call_end(h, dst);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HIPEXEC_OK;
+}
+
+int hipexec_render_device(hipexec_t *h, const hipexec_render_cfg *cfg, float *d_out_rgba, int32_t *d_out_ids,
+                          hipexec_stats *stats)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    CHK(validate_cfg(cfg));
+    if (!d_out_rgba) return fail(HIPEXEC_E_INVALID, "d_out_rgba is NULL");
+    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0));
+    int rc = render_dispatch(h, cfg, reinterpret_cast<float4 *>(d_out_rgba), d_out_ids);
+    if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
+    HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    h->pending_stats = stats;
+    return HIPEXEC_OK;
+}
+
+int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg, float *out_rgb, int32_t *out_ids, hipexec_stats *stats)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    CHK(validate_cfg(cfg));
+    if (!out_rgb) return fail(HIPEXEC_E_INVALID, "out_rgb is NULL");
+    const int spp = cfg->mode == HIPEXEC_MODE_CL ? 1 : 4;
+    const int n_tiles = n_tiles_of(cfg);
+    const size_t rows = (size_t)n_tiles * HIPEXEC_TILE_ROWS, W = (size_t)cfg->width;
+    if (n_tiles == 0) { if (stats) memset(stats, 0, sizeof *stats); return HIPEXEC_OK; }
+    HIPCHK(hipSetDevice(h->device));
+    CHK(h->out_rgba.reserve(rows * W * 16));
+    if (out_ids) CHK(h->out_ids.reserve(rows * W * 4 * spp));
+    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0));
+    int rc = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
+    if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
+    CHK(call_end(h, stats));
+    std::vector<float> rgba(rows * W * 4);
+    HIPCHK(hipMemcpy(rgba.data(), h->out_rgba.p, rgba.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> ids;
+    if (out_ids) { ids.resize(rows * W * spp); HIPCHK(hipMemcpy(ids.data(), h->out_ids.p, ids.size() * 4, hipMemcpyDeviceToHost)); }
+    for (int k = 0; k < n_tiles; k++) {
+        for (int ly = 0; ly < HIPEXEC_TILE_ROWS; ly++) {
+            int y = (cfg->tile_first + k * cfg->tile_step) * HIPEXEC_TILE_ROWS + ly;
+            if (y >= cfg->height) break;
+            size_t lrow = (size_t)k * HIPEXEC_TILE_ROWS + ly;
+            for (size_t x = 0; x < W; x++) {
+                const float *src = &rgba[(lrow * W + x) * 4];
+                float *dst = out_rgb + ((size_t)y * W + x) * 3;
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+            }
+            if (out_ids) memcpy(out_ids + (size_t)y * W * spp, &ids[lrow * W * spp], W * spp * sizeof(int32_t));
+        }
+    }
+    return HIPEXEC_OK;
+}
+
+int hipexec_closest_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, hipexec_hit *out)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (mode != HIPEXEC_MODE_CPU && mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", mode);
+    if (n == 0) return HIPEXEC_OK;
+    if (!rays6 || !out) return fail(HIPEXEC_E_INVALID, "rays6/out is NULL");
+    CHK(call_begin(h, false));
+    for (uint32_t off = 0; off < n; off += BATCH_API_CHUNK) {
+        uint32_t m = std::min(BATCH_API_CHUNK, n - off);
+        CHK(import_rays(h, rays6 + 6 * (size_t)off, m));
+        CHK(h->hit0.reserve((size_t)m * 16));
+        CHK(h->stage_out.reserve((size_t)m * sizeof(hipexec_hit)));
+        if (mode == HIPEXEC_MODE_CL) CHK(launch_closest<HIPEXEC_MODE_CL>(h, h->rayA.as<float4>(), m, h->hit0.as<float4>()));
+        else CHK(launch_closest<HIPEXEC_MODE_CPU>(h, h->rayA.as<float4>(), m, h->hit0.as<float4>()));
+        LAUNCH(HIPEXEC_K_SHADE, k_export_hits, blocks_for(m), h->S, h->rayA.as<float4>(), h->hit0.as<float4>(), m,
+               h->stage_out.as<hipexec_hit>());
+        HIPCHK(hipMemcpyAsync(out + off, h->stage_out.p, (size_t)m * sizeof(hipexec_hit), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return call_end(h, nullptr);
+}
+
+int hipexec_any_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, char *hits)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (mode != HIPEXEC_MODE_CPU && mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", mode);
+    if (n == 0) return HIPEXEC_OK;
+    if (!rays6 || !hits) return fail(HIPEXEC_E_INVALID, "rays6/hits is NULL");
+    CHK(call_begin(h, false));
+    std::vector<uint32_t> bits;
+    for (uint32_t off = 0; off < n; off += BATCH_API_CHUNK) {
+        uint32_t m = std::min(BATCH_API_CHUNK, n - off);
+        CHK(import_rays(h, rays6 + 6 * (size_t)off, m));       // sample index = position, lamp = 0
+        CHK(h->stage_out.reserve((size_t)m * 4));
+        HIPCHK(hipMemsetAsync(h->stage_out.p, 0, (size_t)m * 4, h->stream));
+        if (mode == HIPEXEC_MODE_CL)
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<HIPEXEC_MODE_CL, true>), blocks_for(m), h->S, h->rayA.as<float4>(), m,
+                   h->stage_out.as<uint32_t>(), 1u, h->d_cnt64);
+        else
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<HIPEXEC_MODE_CPU, true>), blocks_for(m), h->S, h->rayA.as<float4>(), m,
+                   h->stage_out.as<uint32_t>(), 1u, h->d_cnt64);
+        bits.resize(m);
+        HIPCHK(hipMemcpyAsync(bits.data(), h->stage_out.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (uint32_t i = 0; i < m; i++) hits[off + i] = (hits[off + i] || (bits[i] & 1u)) ? 1 : 0;
+    }
+    return call_end(h, nullptr);
+}
+
+int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6, uint32_t n, float *colours3,
+                       hipexec_stats *stats)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (mode != HIPEXEC_MODE_CPU && mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", mode);
+    if (max_depth < 0 || max_depth > 64) return fail(HIPEXEC_E_LIMIT, "max_depth %d outside [0,64]", max_depth);
+    if (n == 0) { if (stats) memset(stats, 0, sizeof *stats); return HIPEXEC_OK; }
+    if (!rays6 || !colours3) return fail(HIPEXEC_E_INVALID, "rays6/colours3 is NULL");
+    CHK(call_begin(h, false));
+    const DScene &S = h->S;
+    int depth = mode == HIPEXEC_MODE_CL ? 0 : max_depth;
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(BATCH_API_CHUNK, SHADOW_QUEUE_MAX_ENTRIES / std::max(1u, S.n_lamp)));
+    for (uint32_t off = 0; off < n; off += chunk) {
+        uint32_t m = std::min(chunk, n - off);
+        CHK(reserve_trace_buffers(h, m, depth + 1));
+        CHK(import_rays(h, rays6 + 6 * (size_t)off, m));
+        CHK(h->stage_out.reserve((size_t)m * 12));
+        HIPCHK(hipMemcpyAsync(h->stage_out.p, colours3 + 3 * (size_t)off, (size_t)m * 12, hipMemcpyHostToDevice, h->stream));
+        h->acc.rays_primary += m;
+        h->acc.tests_tri_closest += (uint64_t)m * S.n_tri; h->acc.tests_tri_primary += (uint64_t)m * S.n_tri;
+        h->acc.tests_sph_closest += (uint64_t)m * S.n_sph;
+        int levels_used = 1;
+        if (mode == HIPEXEC_MODE_CL) {
+            CHK(launch_closest<HIPEXEC_MODE_CL>(h, h->rayA.as<float4>(), m, h->hit0.as<float4>()));
+            CHK(trace_levels<HIPEXEC_MODE_CL>(h, m, m, depth, &levels_used));
+        } else {
+            CHK(launch_closest<HIPEXEC_MODE_CPU>(h, h->rayA.as<float4>(), m, h->hit0.as<float4>()));
+            CHK(trace_levels<HIPEXEC_MODE_CPU>(h, m, m, depth, &levels_used));
+        }
+        LAUNCH(HIPEXEC_K_SHADE, k_resolve_batch, blocks_for(m), m, h->local.as<float4>(), (size_t)m, levels_used,
+               h->stage_out.as<float>());
+        HIPCHK(hipMemcpyAsync(colours3 + 3 * (size_t)off, h->stage_out.p, (size_t)m * 12, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return call_end(h, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""Python binding of the C-ABI HIP executor (include/hip_executor.h).
+
+`HipExecutor` plays the role of the reference's `OpenClExecutor` (opencl_executor.h:12-95):
+constructed from a scene, it owns the device copy of the geometry and answers closest-hit /
+any-hit / trace / render requests.  There is no CPU fallback: if the library is missing or a
+call fails, a RuntimeError is raised (the reference throws std::runtime_error,
+opencl_executor.h:67-72).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import HIPEXEC_MODE_CL, HIPEXEC_MODE_CPU, HIPEXEC_TILE_ROWS
+from .scene import FlatScene
+
+
+class HipExecutorError(RuntimeError):
+    pass
+
+
+def n_tiles(height: int, tile_first: int = 0, tile_step: int = 1) -> int:
+    total = (height + HIPEXEC_TILE_ROWS - 1) // HIPEXEC_TILE_ROWS
+    if tile_first >= total:
+        return 0
+    return (total - tile_first + tile_step - 1) // tile_step
+
+
+class HipExecutor:
+    def __init__(self, scene: FlatScene, device: int = -1):
+        self._lib = _abi.load_library()
+        self.scene = scene
+        desc, keep = scene.to_desc()
+        self._h = C.c_void_p()
+        self._check(self._lib.hipexec_create(C.byref(self._h), C.byref(desc), int(device)))
+        del keep
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.hipexec_last_error().decode("utf-8", "replace")
+            raise HipExecutorError(f"hip_executor error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.hipexec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self._lib.hipexec_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def sync(self):
+        self._check(self._lib.hipexec_sync(self._h))
+
+    # -- frame ----------------------------------------------------------------------------
+    @staticmethod
+    def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels):
+        return _abi.RenderCfg(int(width), int(height), int(mode), int(max_depth), int(bool(tone)), int(tile_first),
+                              int(tile_step), _abi.HIPEXEC_FLAG_TIME_KERNELS if time_kernels else 0)
+
+    def render(self, width, height, mode=HIPEXEC_MODE_CPU, max_depth=0, tone=True, tile_first=0, tile_step=1,
+               want_ids=True, time_kernels=False, out=None):
+        """Render to host memory.  -> dict(rgb [H][W][3] float32, ids [H][W][spp] int32 | None, stats)."""
+        spp = 1 if mode == HIPEXEC_MODE_CL else 4
+        rgb = out if out is not None else np.zeros((height, width, 3), np.float32)
+        assert rgb.dtype == np.float32 and rgb.flags.c_contiguous and rgb.shape == (height, width, 3)
+        ids = np.full((height, width, spp), -3, np.int32) if want_ids else None
+        st = _abi.Stats()
+        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels)
+        self._check(self._lib.hipexec_render(self._h, C.byref(cfg), rgb.ctypes.data,
+                                             ids.ctypes.data if ids is not None else None, C.byref(st)))
+        return {"rgb": rgb, "ids": ids, "stats": st}
+
+    def render_device(self, width, height, d_out_rgba: int, d_out_ids: int | None = None, mode=HIPEXEC_MODE_CPU,
+                      max_depth=0, tone=True, tile_first=0, tile_step=1, time_kernels=False, stats=None):
+        """Render into device memory (raw device pointers, e.g. torch.Tensor.data_ptr()).
+        Asynchronous; call sync() before reading `stats`."""
+        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels)
+        self._check(self._lib.hipexec_render_device(self._h, C.byref(cfg), C.c_void_p(d_out_rgba),
+                                                    C.c_void_p(d_out_ids or 0),
+                                                    C.byref(stats) if stats is not None else None))
+
+    # -- batches (ray_tracer_cl.h:29-54) --------------------------------------------------
+    @staticmethod
+    def _rays(rays6):
+        r = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
+        return r
+
+    def closest_hits(self, rays6, mode=HIPEXEC_MODE_CL):
+        r = self._rays(rays6)
+        out = np.zeros(r.shape[0], dtype=_abi.HIT_DTYPE)
+        self._check(self._lib.hipexec_closest_hits(self._h, int(mode), r.ctypes.data, r.shape[0], out.ctypes.data))
+        return out
+
+    def any_hits(self, rays6, mode=HIPEXEC_MODE_CL, hits=None):
+        r = self._rays(rays6)
+        if hits is None:
+            hits = np.zeros(r.shape[0], dtype=np.int8)
+        assert hits.dtype == np.int8 and hits.flags.c_contiguous and hits.shape[0] == r.shape[0]
+        self._check(self._lib.hipexec_any_hits(self._h, int(mode), r.ctypes.data, r.shape[0], hits.ctypes.data))
+        return hits
+
+    def trace_rays(self, rays6, mode=HIPEXEC_MODE_CL, max_depth=0, colours=None, want_stats=False):
+        r = self._rays(rays6)
+        if colours is None:
+            colours = np.zeros((r.shape[0], 3), np.float32)
+        assert colours.dtype == np.float32 and colours.flags.c_contiguous and colours.shape == (r.shape[0], 3)
+        st = _abi.Stats()
+        self._check(self._lib.hipexec_trace_rays(self._h, int(mode), int(max_depth), r.ctypes.data, r.shape[0],
+                                                 colours.ctypes.data, C.byref(st)))
+        return (colours, st) if want_stats else colours
