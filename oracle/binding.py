@@ -40,6 +40,9 @@ def lib():
         L.orc_render_region.restype = None
         L.orc_render_region.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.RenderCfg), C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_abi.Stats), C.c_int]
+        L.orc_render_blocks.restype = None
+        L.orc_render_blocks.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.RenderCfg), C.c_int, C.c_void_p,
+                                        C.POINTER(_abi.Stats), C.c_int]
         _lib = L
     return _lib
 
@@ -112,6 +115,14 @@ class Oracle:
         lib().orc_render_region(C.byref(self.desc), C.byref(cfg), x, y, w, h, rgb.ctypes.data, lin.ctypes.data,
                                 ids.ctypes.data, C.byref(st), n_threads)
         return {"rgb": rgb, "linear": lin, "ids": ids, "stats": st}
+
+    def render_blocks(self, width, height, blocks_xywh, mode=_abi.HIPEXEC_MODE_CPU, max_depth=0, n_threads=1):
+        """Trace the pixels of a list of (x, y, w, h) rectangles, colours discarded -> Stats."""
+        cfg = _abi.RenderCfg(width, height, mode, max_depth, 1, 0, 1, 0)
+        blk = np.ascontiguousarray(blocks_xywh, dtype=np.int32).reshape(-1, 4)
+        st = _abi.Stats()
+        lib().orc_render_blocks(C.byref(self.desc), C.byref(cfg), blk.shape[0], blk.ctypes.data, C.byref(st), n_threads)
+        return st
 
     def render(self, width, height, **kw):
         return self.render_region(width, height, 0, 0, width, height, **kw)

@@ -461,7 +461,10 @@ static void render_block(const job_t *J, int bx, int by, int bw, int bh, hipexec
     }
 }
 
-typedef struct { const job_t *J; int nbx, nby; int next; pthread_mutex_t mu; hipexec_stats st; } pool_t;
+typedef struct {
+    const job_t *J; int n_blocks; const int *blocks;   /* x,y,w,h relative to the region */
+    int next; pthread_mutex_t mu; hipexec_stats st;
+} pool_t;
 
 static void stats_add(hipexec_stats *a, const hipexec_stats *b)
 {
@@ -471,20 +474,18 @@ static void stats_add(hipexec_stats *a, const hipexec_stats *b)
     a->tests_tri_primary += b->tests_tri_primary;
 }
 
-/* taskProcessor, ray_tracer.cpp:124-153: pop a 48x48 block under a mutex, render it */
+/* taskProcessor, ray_tracer.cpp:124-153: pop a block under a mutex, render it */
 static void *worker(void *arg)
 {
     pool_t *P = (pool_t *)arg;
     hipexec_stats local; memset(&local, 0, sizeof local);
     for (;;) {
         pthread_mutex_lock(&P->mu);
-        int k = P->next < P->nbx * P->nby ? P->next++ : -1;
+        int k = P->next < P->n_blocks ? P->next++ : -1;
         pthread_mutex_unlock(&P->mu);
         if (k < 0) break;
-        int bx = (k % P->nbx) * SUB_BLOCK, by = (k / P->nbx) * SUB_BLOCK;
-        int bw = P->J->w - bx < SUB_BLOCK ? P->J->w - bx : SUB_BLOCK;
-        int bh = P->J->h - by < SUB_BLOCK ? P->J->h - by : SUB_BLOCK;
-        render_block(P->J, bx, by, bw, bh, &local);
+        const int *b = P->blocks + 4 * k;
+        render_block(P->J, b[0], b[1], b[2], b[3], &local);
     }
     pthread_mutex_lock(&P->mu);
     stats_add(&P->st, &local);
@@ -492,14 +493,10 @@ static void *worker(void *arg)
     return NULL;
 }
 
-void orc_render_region(const hipexec_scene_desc *s, const hipexec_render_cfg *cfg,
-                       int x, int y, int w, int h,
-                       float *out_rgb, float *out_linear, int32_t *out_ids,
-                       hipexec_stats *stats, int n_threads)
+static void run_pool(const job_t *J, int n_blocks, const int *blocks, hipexec_stats *stats, int n_threads)
 {
-    job_t J = {s, cfg, x, y, w, h, out_rgb, out_linear, out_ids};
     pool_t P; memset(&P, 0, sizeof P);
-    P.J = &J; P.nbx = (w + SUB_BLOCK - 1) / SUB_BLOCK; P.nby = (h + SUB_BLOCK - 1) / SUB_BLOCK;
+    P.J = J; P.n_blocks = n_blocks; P.blocks = blocks;
     pthread_mutex_init(&P.mu, NULL);
     if (n_threads <= 1) {
         worker(&P);
@@ -511,4 +508,33 @@ void orc_render_region(const hipexec_scene_desc *s, const hipexec_render_cfg *cf
     }
     pthread_mutex_destroy(&P.mu);
     if (stats) stats_add(stats, &P.st);
+}
+
+void orc_render_region(const hipexec_scene_desc *s, const hipexec_render_cfg *cfg,
+                       int x, int y, int w, int h,
+                       float *out_rgb, float *out_linear, int32_t *out_ids,
+                       hipexec_stats *stats, int n_threads)
+{
+    job_t J = {s, cfg, x, y, w, h, out_rgb, out_linear, out_ids};
+    /* block list of renderParallel, ray_tracer.cpp:69-113 (48x48 blocks, ragged right/bottom) */
+    int nbx = (w + SUB_BLOCK - 1) / SUB_BLOCK, nby = (h + SUB_BLOCK - 1) / SUB_BLOCK;
+    int *blocks = (int *)malloc(sizeof(int) * 4 * (size_t)(nbx * nby > 0 ? nbx * nby : 1));
+    int n = 0;
+    for (int j = 0; j < nby; j++)
+        for (int i = 0; i < nbx; i++) {
+            int bx = i * SUB_BLOCK, by = j * SUB_BLOCK;
+            blocks[4 * n] = bx; blocks[4 * n + 1] = by;
+            blocks[4 * n + 2] = w - bx < SUB_BLOCK ? w - bx : SUB_BLOCK;
+            blocks[4 * n + 3] = h - by < SUB_BLOCK ? h - by : SUB_BLOCK;
+            n++;
+        }
+    run_pool(&J, n, blocks, stats, n_threads);
+    free(blocks);
+}
+
+void orc_render_blocks(const hipexec_scene_desc *s, const hipexec_render_cfg *cfg,
+                       int n_blocks, const int *blocks_xywh, hipexec_stats *stats, int n_threads)
+{
+    job_t J = {s, cfg, 0, 0, cfg->width, cfg->height, NULL, NULL, NULL};
+    run_pool(&J, n_blocks, blocks_xywh, stats, n_threads);
 }

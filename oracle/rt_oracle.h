@@ -66,6 +66,12 @@ void orc_render_region(const hipexec_scene_desc *s, const hipexec_render_cfg *cf
                        float *out_rgb, float *out_linear, int32_t *out_ids,
                        hipexec_stats *stats, int n_threads);
 
+/* Traces the pixels of n_blocks rectangles {x,y,w,h} of the full frame on a pool of n_threads
+ * workers and discards the colours; only `stats` is produced.  Used to time the CPU baseline
+ * on a bounded sample of a large frame. */
+void orc_render_blocks(const hipexec_scene_desc *s, const hipexec_render_cfg *cfg,
+                       int n_blocks, const int *blocks_xywh, hipexec_stats *stats, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif
