@@ -132,6 +132,9 @@ typedef struct hipexec_stats {
     uint64_t tests_tri_any;       /* ray-triangle tests of shadow rays (reference order)    */
     uint64_t tests_sph_any;
     uint64_t tests_tri_primary;   /* part of tests_tri_closest due to primary rays          */
+    uint64_t exact_groups[3];     /* per kernel class (primary, closest, any-hit): number of
+                                     (wave, triangle group) pairs that left the filter-only path
+                                     for exact tests; a diagnostic of filter selectivity        */
     uint32_t launches[HIPEXEC_K_COUNT];
     float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */
     float    total_ms;                     /* HIP-event time of the whole call on its stream */

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -68,7 +69,9 @@ struct hipexec {
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;
     Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
-    uint32_t *d_cnt32 = nullptr;              // [0] shadow queue fill, [1] next-level queue fill
+    uint32_t *d_cnt32 = nullptr;              // [0] next-level queue fill, [1 + l] shadow queue fill of lamp l
+    uint32_t n_cnt32 = 0;
+    int closest_r = 2, anyhit_r = 2;          // rays per lane (tunable through HIPEXEC_CLOSEST_R / HIPEXEC_ANYHIT_R)
     unsigned long long *d_cnt64 = nullptr;    // [0] any-hit triangle tests, [1] any-hit sphere tests
     uint32_t *h_cnt32 = nullptr;              // pinned
     unsigned long long *h_cnt64 = nullptr;    // pinned
@@ -90,8 +93,13 @@ int upload(hipexec *h, const T *src, size_t count, T **dst, size_t min_count = 1
     void *p = nullptr;
     HIPCHK(hipMalloc(&p, n * sizeof(T)));
     h->scene_allocs.push_back(p);
-    HIPCHK(hipMemset(p, 0, n * sizeof(T)));
-    if (count && src) HIPCHK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    // everything goes through the executor's stream: its set-up kernels run there and a
+    // non-blocking stream is not ordered against the null stream
+    HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), h->stream));
+    if (count && src) {
+        HIPCHK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));      // src may be a temporary of the caller
+    }
     *dst = reinterpret_cast<T *>(p);
     return HIPEXEC_OK;
 }
@@ -142,25 +150,49 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         grow(p[0], p[1], p[2]); grow(p[0] + a[0], p[1] + a[1], p[2] + a[2]); grow(p[0] + b[0], p[1] + b[1], p[2] + b[2]);
     }
     for (uint32_t i = 0; i < s->n_sph; i++) grow(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2]);
+    grow(s->cam_pos[0], s->cam_pos[1], s->cam_pos[2]);
     for (int k = 0; k < 3; k++) S.center[k] = (lo[k] <= hi[k]) ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
+    // Radius around the centre that contains every vertex, sphere and the camera (+10 %): ray
+    // origins on surfaces lie inside it; the FILTER widens its threshold for farther origins.
+    double r2 = 0.0;
+    for (int k = 0; k < 3; k++) { double e = (lo[k] <= hi[k]) ? 0.5 * (hi[k] - lo[k]) : 0.0; r2 += e * e; }
+    double rs = 0.0;
+    for (uint32_t i = 0; i < s->n_sph; i++) if (std::isfinite(s->sph_radius[i])) rs = std::max(rs, (double)std::fabs(s->sph_radius[i]));
+    S.rmax = (float)std::max(1e-3, 1.1 * (std::sqrt(r2) + rs));
+    {
+        const char *nf = getenv("HIPEXEC_NO_FILTER");     // verification aid: every pair takes the exact path
+        S.theta = (nf && nf[0] == '1') ? 3.0e38f : 1.001f;
+    }
 
     // triangles
     float *d_p = nullptr, *d_e1 = nullptr, *d_e2 = nullptr;
     CHK(upload(h, s->tri_p, 3 * (size_t)s->n_tri, &d_p));
     CHK(upload(h, s->tri_e1, 3 * (size_t)s->n_tri, &d_e1));
     CHK(upload(h, s->tri_e2, 3 * (size_t)s->n_tri, &d_e2));
-    float4 *ex = nullptr, *px = nullptr, *fp = nullptr, *fg = nullptr;
+    float4 *ex = nullptr, *px = nullptr; PairCam *pc = nullptr; PairGen *pg = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &ex, 3 * (size_t)S.n_tri_pad + 1));
     CHK(upload<float4>(h, nullptr, 0, &px, 3 * (size_t)S.n_tri_pad + 1));
-    CHK(upload<float4>(h, nullptr, 0, &fp, 3 * (size_t)S.n_tri_pad + 1));
-    CHK(upload<float4>(h, nullptr, 0, &fg, 5 * (size_t)S.n_tri_pad + 1));
+    CHK(upload<PairCam>(h, nullptr, 0, &pc, (size_t)S.n_tri_pad / 2 + 1));
+    CHK(upload<PairGen>(h, nullptr, 0, &pg, (size_t)S.n_tri_pad / 2 + 1));
     if (S.n_tri_pad) {
         f3 cam = {S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]}, cen = {S.center[0], S.center[1], S.center[2]};
-        hipLaunchKernelGGL(k_setup_triangles, dim3((S.n_tri_pad + 255) / 256), dim3(256), 0, h->stream,
-                           S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, cam, cen, ex, px, fp, fg);
+        hipLaunchKernelGGL(k_setup_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                           S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, cam, cen, S.rmax, ex, px, pc, pg);
         HIPCHK(hipGetLastError());
     }
-    S.tri_exact = ex; S.tri_primx = px; S.tri_fastp = fp; S.tri_fastg = fg;
+    S.tri_exact = ex; S.tri_primx = px; S.pair_cam = pc; S.pair_gen = pg;
+    PairCam *pl = nullptr;
+    CHK(upload<PairCam>(h, nullptr, 0, &pl, (size_t)s->n_lamp * (S.n_tri_pad / 2) + 1));
+    if (S.n_tri_pad) {
+        float abs_bound = S.rmax + std::sqrt(S.center[0] * S.center[0] + S.center[1] * S.center[1] + S.center[2] * S.center[2]);
+        for (uint32_t l = 0; l < s->n_lamp; l++) {
+            f3 L = {s->lamp_pos[3 * l], s->lamp_pos[3 * l + 1], s->lamp_pos[3 * l + 2]};
+            hipLaunchKernelGGL(k_setup_lamp_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                               S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, L, abs_bound, pl + (size_t)l * (S.n_tri_pad / 2));
+            HIPCHK(hipGetLastError());
+        }
+    }
+    S.pair_lamp = pl;
     float *d_norm = nullptr, *d_uv = nullptr; int *d_tmat = nullptr;
     CHK(upload(h, s->tri_norm, 3 * (size_t)s->n_tri, &d_norm));
     CHK(upload(h, s->tri_uv, s->tri_uv ? 6 * (size_t)s->n_tri : 0, &d_uv, 6 * (size_t)std::max(1u, s->n_tri)));
@@ -252,7 +284,7 @@ int call_begin(hipexec *h, bool timing)
     h->timing = timing;
     memset(&h->acc, 0, sizeof h->acc);
     h->call_open = true;
-    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 8 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     return HIPEXEC_OK;
 }
@@ -261,10 +293,11 @@ int call_begin(hipexec *h, bool timing)
 int call_end(hipexec *h, hipexec_stats *stats)
 {
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->acc.tests_tri_any = h->h_cnt64[0];
     h->acc.tests_sph_any = h->h_cnt64[1];
+    for (int k = 0; k < 3; k++) h->acc.exact_groups[k] = h->h_cnt64[2 + k];
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {
         float ms = 0.f;
@@ -287,12 +320,48 @@ int read_count(hipexec *h, int which, uint32_t *out)
 }
 
 template <int MODE>
-int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
+int launch_anyhit(hipexec *h, const float4 *rays, uint32_t n, uint32_t *occl, uint32_t lw)
 {
     constexpr int R = 2;
     uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
-    LAUNCH(HIPEXEC_K_CLOSEST, (k_closest<MODE, R, true>), blocks_for(waves * 64), h->S, rays, n, hits);
+    LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<MODE, R>), blocks_for(waves * 64), h->S, rays, n, occl, lw, h->d_cnt64);
     return HIPEXEC_OK;
+}
+
+template <int MODE, int R>
+int launch_anyhit_lamp_r(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t n, uint32_t *occl, uint32_t lw)
+{
+    uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
+    const PairCam *pl = h->S.pair_lamp + (size_t)lamp * (h->S.n_tri_pad / 2);
+    LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit_lamp<MODE, R>), blocks_for(waves * 64), h->S, pl, rays, n, occl, lw, h->d_cnt64);
+    return HIPEXEC_OK;
+}
+template <int MODE>
+int launch_anyhit_lamp(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t n, uint32_t *occl, uint32_t lw)
+{
+    switch (h->anyhit_r) {
+    case 1: return launch_anyhit_lamp_r<MODE, 1>(h, lamp, rays, n, occl, lw);
+    case 4: return launch_anyhit_lamp_r<MODE, 4>(h, lamp, rays, n, occl, lw);
+    default: return launch_anyhit_lamp_r<MODE, 2>(h, lamp, rays, n, occl, lw);
+    }
+}
+
+template <int MODE, int R>
+int launch_closest_r(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
+{
+    uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
+    LAUNCH(HIPEXEC_K_CLOSEST, (k_closest<MODE, R>), blocks_for(waves * 64), h->S, rays, n, hits, h->d_cnt64);
+    return HIPEXEC_OK;
+}
+template <int MODE>
+int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
+{
+    switch (h->closest_r) {
+    case 1: return launch_closest_r<MODE, 1>(h, rays, n, hits);
+    case 3: return launch_closest_r<MODE, 3>(h, rays, n, hits);
+    case 4: return launch_closest_r<MODE, 4>(h, rays, n, hits);
+    default: return launch_closest_r<MODE, 2>(h, rays, n, hits);
+    }
 }
 
 // Shadow rays, shading and bounces for n0 level-0 rays whose records are in rayA and whose
@@ -307,25 +376,25 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
     int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : std::max(0, max_depth);
     int level = 0;
     for (;; level++) {
+        HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
         if (S.n_lamp) {
-            HIPCHK(hipMemsetAsync(h->d_cnt32, 0, 2 * sizeof(uint32_t), h->stream));
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
-                   h->shadowq.as<float4>(), h->d_cnt32);
-            uint32_t nsh = 0;
-            CHK(read_count(h, 0, &nsh));
-            h->acc.rays_shadow += nsh;
-            if (nsh)
-                LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<MODE, true>), blocks_for(nsh), S, h->shadowq.as<float4>(), nsh,
-                       h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64);
-        } else {
-            HIPCHK(hipMemsetAsync(h->d_cnt32, 0, 2 * sizeof(uint32_t), h->stream));
+                   h->shadowq.as<float4>(), h->d_cnt32 + 1);
+            HIPCHK(hipMemcpyAsync(h->h_cnt32 + 1, h->d_cnt32 + 1, S.n_lamp * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (uint32_t l = 0; l < S.n_lamp; l++) {
+                uint32_t nsh = h->h_cnt32[1 + l];
+                h->acc.rays_shadow += nsh;
+                if (nsh) CHK(launch_anyhit_lamp<MODE>(h, l, h->shadowq.as<float4>() + 2 * (size_t)l * n, nsh,
+                                                      h->occl.as<uint32_t>(), h->lamp_words));
+            }
         }
         bool spawn = level < depth;
         LAUNCH(HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
-               h->lamp_words, h->local.as<float4>() + (size_t)level * stride, spawn, next_rays, h->d_cnt32 + 1);
+               h->lamp_words, h->local.as<float4>() + (size_t)level * stride, spawn, next_rays, h->d_cnt32);
         if (!spawn) break;
         uint32_t nn = 0;
-        CHK(read_count(h, 1, &nn));
+        CHK(read_count(h, 0, &nn));
         if (nn == 0) break;
         h->acc.rays_bounce += nn;
         h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
@@ -392,7 +461,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         uint64_t n0 = (uint64_t)F.n_slots * SPP;
         if (n0 > 0xfffffff0ull) return fail(HIPEXEC_E_LIMIT, "batch of %llu samples exceeds 32-bit indexing", (unsigned long long)n0);
         CHK(reserve_trace_buffers(h, n0, depth + 1));
-        LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE, true>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>());
+        LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>(), h->d_cnt64);
         int rows = std::min(F.n_tiles * HIPEXEC_TILE_ROWS, c->height - F.tile_first * HIPEXEC_TILE_ROWS);
         if (c->tile_step != 1) {
             rows = 0;
@@ -466,12 +535,15 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
         h->stream = h->own_stream;
         HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end));
-        HIPCHK(hipMalloc((void **)&h->d_cnt32, 8 * sizeof(uint32_t)));
-        HIPCHK(hipMalloc((void **)&h->d_cnt64, 4 * sizeof(unsigned long long)));
-        HIPCHK(hipHostMalloc((void **)&h->h_cnt32, 8 * sizeof(uint32_t), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&h->h_cnt64, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-        HIPCHK(hipMemset(h->d_cnt32, 0, 8 * sizeof(uint32_t)));
-        HIPCHK(hipMemset(h->d_cnt64, 0, 4 * sizeof(unsigned long long)));
+        h->n_cnt32 = std::max(8u, scene->n_lamp + 1u);
+        HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&h->d_cnt64, 8 * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h->h_cnt64, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
+        if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
+        if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
+        HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 8 * sizeof(unsigned long long), h->stream));
         return build_scene(h, scene);
     }();
     if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
@@ -606,12 +678,8 @@ int hipexec_any_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, cha
         CHK(import_rays(h, rays6 + 6 * (size_t)off, m));       // sample index = position, lamp = 0
         CHK(h->stage_out.reserve((size_t)m * 4));
         HIPCHK(hipMemsetAsync(h->stage_out.p, 0, (size_t)m * 4, h->stream));
-        if (mode == HIPEXEC_MODE_CL)
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<HIPEXEC_MODE_CL, true>), blocks_for(m), h->S, h->rayA.as<float4>(), m,
-                   h->stage_out.as<uint32_t>(), 1u, h->d_cnt64);
-        else
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<HIPEXEC_MODE_CPU, true>), blocks_for(m), h->S, h->rayA.as<float4>(), m,
-                   h->stage_out.as<uint32_t>(), 1u, h->d_cnt64);
+        if (mode == HIPEXEC_MODE_CL) CHK(launch_anyhit<HIPEXEC_MODE_CL>(h, h->rayA.as<float4>(), m, h->stage_out.as<uint32_t>(), 1u));
+        else CHK(launch_anyhit<HIPEXEC_MODE_CPU>(h, h->rayA.as<float4>(), m, h->stage_out.as<uint32_t>(), 1u));
         bits.resize(m);
         HIPCHK(hipMemcpyAsync(bits.data(), h->stage_out.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

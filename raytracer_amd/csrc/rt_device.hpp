@@ -42,7 +42,32 @@ DEV f3 xyz(float4 a) { return mk(a.x, a.y, a.z); }
 
 // Scene in device memory.  Triangle arrays are padded to a multiple of TRI_PAD records with
 // records no ray can hit.
-constexpr int TRI_PAD = 8;
+constexpr int TRI_PAD = 128;   // = 2 * LDS_CHUNK triangles: whole LDS chunks of triangle pairs
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// FILTER record of a pair of triangles (2j, 2j+1) for camera rays; every member holds the
+// value of triangle 2j in .x and of triangle 2j+1 in .y so that one packed FP32 instruction
+// (v_pk_fma_f32 / v_pk_mul_f32) evaluates both.  Edge functions are scaled by 1/slack, so a
+// pair "may hit" iff min(u, v, w) >= -theta with theta ~ 1.
+struct PairCam {
+    v2f ux, uy, uz;      // s * cross(e2, q) / slack
+    v2f vx, vy, vz;      // s * cross(q, e1) / slack
+    v2f wx, wy, wz;      // s * (c21 - ceq - cqe) / slack
+    v2f pad;
+};
+// A record that must never pass (padding, zero-area triangles) has ux = +1e30, vx = -1e30 and
+// zeros elsewhere: min(u,v,w) = -1e30*|d.x| and max(u,v,w) = +1e30*|d.x| fail both tests for
+// every direction with |d.x| > 1e-30 (the rest merely take the exact path, which rejects).
+// The same record layout, without the sign factor s and with q taken from a lamp instead of
+// the camera, serves shadow rays (all shadow rays of a lamp lie on lines through the lamp).
+// FILTER record of a pair of triangles for arbitrary rays (see k_setup_pairs)
+struct PairGen {
+    v2f ud[3], um[3];    // u = dot(ud, d) + dot(um, mo)
+    v2f vd[3], vm[3];    // v = dot(vd, d) + dot(vm, mo)
+    v2f wd[3], wm[3];    // w = dot(wd, d) + dot(wm, mo)
+};
+static_assert(sizeof(PairCam) == 80 && sizeof(PairGen) == 144, "record sizes");
 
 struct DScene {
     uint32_t n_tri, n_tri_pad, n_sph, n_lamp, n_mat;
@@ -50,10 +75,9 @@ struct DScene {
     const float4 *tri_exact;
     // EXACT camera-ray records, 3 float4: {c21, dett} {cross(e2,q), 0} {cross(q,e1), 0}, q = cam_pos - p
     const float4 *tri_primx;
-    // FILTER camera-ray records, 3 float4: {s*cross(e2,q), slack} {s*cross(q,e1), 0} {s*(c21-ceq-cqe), 0}
-    const float4 *tri_fastp;
-    // FILTER records for arbitrary rays, 5 float4 (see k_setup_triangles)
-    const float4 *tri_fastg;
+    const PairCam *pair_cam;  // [n_tri_pad / 2]
+    const PairGen *pair_gen;  // [n_tri_pad / 2]
+    const PairCam *pair_lamp; // [n_lamp][n_tri_pad / 2], edge functions of lines through lamp l
     const float *tri_norm;   // [n][3]
     const float *tri_uv;     // [n][6]
     const int *tri_mat;      // [n]  (index n_mat = default material)
@@ -66,6 +90,8 @@ struct DScene {
     const float *lamp_dist;
     float cam_pos[3], cam_mat[9], horizon[3], ambient[3];
     float center[3];         // translation used by the FILTER records only
+    float rmax;              // radius around `center` the FILTER slack was computed for
+    float theta;             // FILTER threshold scale: 1.001 normally, 3e38 disables the filter
 };
 
 // ---------------------------------------------------------------------------------------

@@ -43,106 +43,210 @@ DEV void store_ray(float4 *rays, uint32_t j, f3 o, f3 d, uint32_t s, uint32_t au
 // scene set-up: per-triangle records (runs once per hipexec_create)
 // ---------------------------------------------------------------------------------------
 constexpr float FILTER_KAPPA = 4e-6f;   // slack factor of the FILTER tests, ~5x the rounding bound
+constexpr float FILTER_NEVER = 1e30f;   // coefficient of a record that must never pass
 
-__global__ void k_setup_triangles(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,
-                                  f3 cam, f3 center, float4 *tri_exact, float4 *tri_primx, float4 *tri_fastp,
-                                  float4 *tri_fastg)
+DEV void set_half(v2f &dst, int h, float v) { if (h) dst.y = v; else dst.x = v; }
+DEV void set_cam_half(PairCam &pc, int h, f3 cu, f3 cv, f3 cw) {
+    set_half(pc.ux, h, cu.x); set_half(pc.uy, h, cu.y); set_half(pc.uz, h, cu.z);
+    set_half(pc.vx, h, cv.x); set_half(pc.vy, h, cv.y); set_half(pc.vz, h, cv.z);
+    set_half(pc.wx, h, cw.x); set_half(pc.wy, h, cw.y); set_half(pc.wz, h, cw.z);
+    set_half(pc.pad, h, 0.f);
+}
+
+// One thread per pair of triangles (2j, 2j+1).  `rmax` bounds the distance of ray origins
+// from `center` the general FILTER slack is valid for (farther origins scale their threshold).
+__global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,
+                              f3 cam, f3 center, float rmax, float4 *tri_exact, float4 *tri_primx,
+                              PairCam *pair_cam, PairGen *pair_gen)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * j >= n_pad) return;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i >= n_tri) {   // padding: det == 0 for every ray, FILTER slack < 0 rejects everything
-        tri_exact[3 * i] = z; tri_exact[3 * i + 1] = z; tri_exact[3 * i + 2] = z;
-        tri_primx[3 * i] = z; tri_primx[3 * i + 1] = z; tri_primx[3 * i + 2] = z;
-        tri_fastp[3 * i] = make_float4(0.f, 0.f, 0.f, -1.f); tri_fastp[3 * i + 1] = z; tri_fastp[3 * i + 2] = z;
-        for (int k = 0; k < 4; k++) tri_fastg[5 * i + k] = z;
-        tri_fastg[5 * i + 4] = make_float4(0.f, 0.f, -1.f, -1.f);
-        return;
+    PairCam pc; PairGen pg;
+    for (int h = 0; h < 2; h++) {
+        uint32_t i = 2 * j + h;
+        f3 zero = mk(0.f, 0.f, 0.f);
+        // default: never passes (padding, zero-area triangles)
+        f3 cu = mk(FILTER_NEVER, 0.f, 0.f), cv = mk(-FILTER_NEVER, 0.f, 0.f), cw = zero;
+        f3 ud = mk(FILTER_NEVER, 0.f, 0.f), um = zero, vd = mk(-FILTER_NEVER, 0.f, 0.f), vm = zero, wd = zero, wm = zero;
+        if (i >= n_tri) {
+            tri_exact[3 * i] = z; tri_exact[3 * i + 1] = z; tri_exact[3 * i + 2] = z;
+            tri_primx[3 * i] = z; tri_primx[3 * i + 1] = z; tri_primx[3 * i + 2] = z;
+        } else {
+            f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
+            f3 e1 = mk(te1[3 * i], te1[3 * i + 1], te1[3 * i + 2]);
+            f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
+            // EXACT: same operations as the per-ray code of the reference
+            f3 c21 = cross(e2, e1);
+            tri_exact[3 * i] = make_float4(p.x, p.y, p.z, c21.x);
+            tri_exact[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, c21.y);
+            tri_exact[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, c21.z);
+            f3 q = cam - p;
+            float dett = dot(q, cross(e1, e2));
+            f3 ceq = cross(e2, q);
+            f3 cqe = cross(q, e1);
+            tri_primx[3 * i] = make_float4(c21.x, c21.y, c21.z, dett);
+            tri_primx[3 * i + 1] = make_float4(ceq.x, ceq.y, ceq.z, 0.f);
+            tri_primx[3 * i + 2] = make_float4(cqe.x, cqe.y, cqe.z, 0.f);
+            float nc = sqrtf(dot(c21, c21)), nu = sqrtf(dot(ceq, ceq)), nv = sqrtf(dot(cqe, cqe));
+            f3 pp = p - center;
+            float ne = sqrtf(dot(e1, e1)) + sqrtf(dot(e2, e2));
+            float slack_c = FILTER_KAPPA * (nc + nu + nv);
+            float slack_g = FILTER_KAPPA * (ne * (rmax + sqrtf(dot(pp, pp))) + nc);
+            bool finite = (slack_c < 3.0e38f) && (slack_g < 3.0e38f);
+            if (!finite) {
+                // let the exact test decide: all-zero records always pass
+                cu = zero; cv = zero; ud = zero; vd = zero;
+            } else if (nc > 0.f) {
+                // camera rays: a hit needs t = dett/det > 0, i.e. sign(det) = sign(dett) = s; with
+                // everything multiplied by s the three edge functions must be >= 0 (up to slack)
+                float s = dett > 0.f ? 1.f : (dett < 0.f ? -1.f : 0.f);
+                if (s != 0.f) {
+                    float k = s / slack_c;
+                    cu = ceq * k; cv = cqe * k; cw = ((c21 - ceq) - cqe) * k;
+                }
+                // arbitrary rays, coordinates translated by -center: with o' = o - center,
+                // mo = cross(o', d), p' = p - center, k1 = cross(p', e1), k2 = cross(e2, p'):
+                //   detu = dot(e2, mo) - dot(d, k2)
+                //   detv = -dot(e1, mo) - dot(d, k1)
+                //   w    = det - detu - detv = dot(d, c21 + k2 + k1) + dot(e1 - e2, mo)
+                f3 k1 = cross(pp, e1), k2 = cross(e2, pp);
+                float g = 1.0f / slack_g;
+                ud = (-k2) * g; um = e2 * g;
+                vd = (-k1) * g; vm = (-e1) * g;
+                wd = ((c21 + k2) + k1) * g; wm = (e1 - e2) * g;
+            }
+            // nc == 0: det == 0 for every ray, the exact tests always reject -> never passes
+        }
+        set_cam_half(pc, h, cu, cv, cw);
+        set_half(pg.ud[0], h, ud.x); set_half(pg.ud[1], h, ud.y); set_half(pg.ud[2], h, ud.z);
+        set_half(pg.um[0], h, um.x); set_half(pg.um[1], h, um.y); set_half(pg.um[2], h, um.z);
+        set_half(pg.vd[0], h, vd.x); set_half(pg.vd[1], h, vd.y); set_half(pg.vd[2], h, vd.z);
+        set_half(pg.vm[0], h, vm.x); set_half(pg.vm[1], h, vm.y); set_half(pg.vm[2], h, vm.z);
+        set_half(pg.wd[0], h, wd.x); set_half(pg.wd[1], h, wd.y); set_half(pg.wd[2], h, wd.z);
+        set_half(pg.wm[0], h, wm.x); set_half(pg.wm[1], h, wm.y); set_half(pg.wm[2], h, wm.z);
     }
-    f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
-    f3 e1 = mk(te1[3 * i], te1[3 * i + 1], te1[3 * i + 2]);
-    f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
-    // EXACT: same operations as the per-ray code of the reference
-    f3 c21 = cross(e2, e1);
-    tri_exact[3 * i] = make_float4(p.x, p.y, p.z, c21.x);
-    tri_exact[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, c21.y);
-    tri_exact[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, c21.z);
-    f3 q = cam - p;
-    float dett = dot(q, cross(e1, e2));
-    f3 ceq = cross(e2, q);
-    f3 cqe = cross(q, e1);
-    tri_primx[3 * i] = make_float4(c21.x, c21.y, c21.z, dett);
-    tri_primx[3 * i + 1] = make_float4(ceq.x, ceq.y, ceq.z, 0.f);
-    tri_primx[3 * i + 2] = make_float4(cqe.x, cqe.y, cqe.z, 0.f);
-    // FILTER for camera rays: a hit needs t = dett/det > 0, i.e. sign(det) = sign(dett) = s, so
-    // with everything multiplied by s the three edge functions must be >= 0 (up to slack).
-    float nc = sqrtf(dot(c21, c21)), nu = sqrtf(dot(ceq, ceq)), nv = sqrtf(dot(cqe, cqe));
-    float s = dett > 0.f ? 1.f : (dett < 0.f ? -1.f : 0.f);
-    float slack = FILTER_KAPPA * (nc + nu + nv);
-    if (s == 0.f || !(slack < 3.0e38f)) {
-        // dett == 0: t == 0 can never pass.  Non-finite data: let the exact test decide.
-        bool reject = (s == 0.f) && (slack < 3.0e38f);
-        tri_fastp[3 * i] = make_float4(0.f, 0.f, 0.f, reject ? -1.f : 3.0e38f);
-        tri_fastp[3 * i + 1] = z; tri_fastp[3 * i + 2] = z;
-    } else {
-        f3 cw = (c21 - ceq) - cqe;
-        tri_fastp[3 * i] = make_float4(s * ceq.x, s * ceq.y, s * ceq.z, slack);
-        tri_fastp[3 * i + 1] = make_float4(s * cqe.x, s * cqe.y, s * cqe.z, 0.f);
-        tri_fastp[3 * i + 2] = make_float4(s * cw.x, s * cw.y, s * cw.z, 0.f);
+    pair_cam[j] = pc;
+    pair_gen[j] = pg;
+}
+
+// FILTER records of the lines through one lamp position L: a shadow ray is (P, L - P), which
+// lies on the line through L with direction d = L - P up to the rounding of that subtraction.
+// With q = L - p the edge functions dot(d, cross(e2,q)), dot(d, cross(q,e1)) and
+// w = dot(d, c21) - u - v have one sign on lines that pierce the triangle.  The slack covers
+// the rounding of the chains and the offset between the two lines (<= 2^-23 * (|L| + |P|),
+// |P| <= abs_bound for hit points of this scene).
+__global__ void k_setup_lamp_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,
+                                   f3 L, float abs_bound, PairCam *pair_lamp)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * j >= n_pad) return;
+    PairCam pc;
+    for (int h = 0; h < 2; h++) {
+        uint32_t i = 2 * j + h;
+        f3 zero = mk(0.f, 0.f, 0.f);
+        f3 cu = mk(FILTER_NEVER, 0.f, 0.f), cv = mk(-FILTER_NEVER, 0.f, 0.f), cw = zero;
+        if (i < n_tri) {
+            f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
+            f3 e1 = mk(te1[3 * i], te1[3 * i + 1], te1[3 * i + 2]);
+            f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
+            f3 c21 = cross(e2, e1);
+            f3 q = L - p;
+            f3 ceq = cross(e2, q), cqe = cross(q, e1);
+            float nc = sqrtf(dot(c21, c21)), nu = sqrtf(dot(ceq, ceq)), nv = sqrtf(dot(cqe, cqe));
+            float ne = sqrtf(dot(e1, e1)) + sqrtf(dot(e2, e2));
+            float slack = FILTER_KAPPA * ((nc + nu + nv) + ne * (sqrtf(dot(L, L)) + abs_bound));
+            if (!(slack < 3.0e38f)) { cu = zero; cv = zero; }
+            else if (nc > 0.f) {
+                float k = 1.0f / slack;
+                cu = ceq * k; cv = cqe * k; cw = ((c21 - ceq) - cqe) * k;
+            }
+        }
+        set_cam_half(pc, h, cu, cv, cw);
     }
-    // FILTER for arbitrary rays, in coordinates translated by -center.  With o' = o - center,
-    // mo = cross(o', d), p' = p - center, k1 = cross(p', e1), k2 = cross(e2, p'):
-    //   detu = dot(e2, mo) - dot(d, k2)
-    //   detv = -dot(e1, mo) - dot(d, k1)
-    //   w    = det - detu - detv = dot(d, c21 + k2 + k1) + dot(e1 - e2, mo)
-    f3 pp = p - center;
-    f3 k1 = cross(pp, e1), k2 = cross(e2, pp);
-    f3 cwd = (c21 + k2) + k1, cwm = e1 - e2;
-    float ne = sqrtf(dot(e1, e1)) + sqrtf(dot(e2, e2));
-    float A = FILTER_KAPPA * ne;
-    float B = FILTER_KAPPA * (ne * sqrtf(dot(pp, pp)) + nc);
-    if (!(A < 3.0e38f) || !(B < 3.0e38f)) { A = 3.0e38f; B = 3.0e38f; }
-    tri_fastg[5 * i] = make_float4(-k2.x, -k2.y, -k2.z, e2.x);
-    tri_fastg[5 * i + 1] = make_float4(e2.y, e2.z, -k1.x, -k1.y);
-    tri_fastg[5 * i + 2] = make_float4(-k1.z, -e1.x, -e1.y, -e1.z);
-    tri_fastg[5 * i + 3] = make_float4(cwd.x, cwd.y, cwd.z, cwm.x);
-    tri_fastg[5 * i + 4] = make_float4(cwm.y, cwm.z, A, B);
+    pair_lamp[j] = pc;
 }
 
 // ---------------------------------------------------------------------------------------
-// FILTER tests
+// FILTER tests (packed FP32: one instruction evaluates both triangles of a pair)
 // ---------------------------------------------------------------------------------------
-DEV float dot3_fma(float ax, float ay, float az, f3 b) { return fmaf(az, b.z, fmaf(ay, b.y, ax * b.x)); }
+DEV v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+DEV v2f splat(float s) { v2f r; r.x = s; r.y = s; return r; }
+DEV float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+DEV float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+#define RT_HALF(v, h) ((h) ? (v).y : (v).x)
 
-// camera ray vs FILTER camera record; true = may be a hit
-DEV bool filter_cam(f3 d, float4 a, float4 b, float4 c) {
-    float su = dot3_fma(a.x, a.y, a.z, d);
-    float sv = dot3_fma(b.x, b.y, b.z, d);
-    float sw = dot3_fma(c.x, c.y, c.z, d);
-    float m = fminf(fminf(su, sv), sw);
-    return !(m < -a.w);
+// the three edge functions of both triangles of a pair for one direction (as splat pairs)
+DEV void edges_cam_pair(const PairCam &P, v2f Dx, v2f Dy, v2f Dz, v2f &su, v2f &sv, v2f &sw) {
+    su = pk_fma(P.uz, Dz, pk_fma(P.uy, Dy, P.ux * Dx));
+    sv = pk_fma(P.vz, Dz, pk_fma(P.vy, Dy, P.vx * Dx));
+    sw = pk_fma(P.wz, Dz, pk_fma(P.wy, Dy, P.wx * Dx));
+}
+DEV void edges_cam_one(const PairCam &P, int h, f3 d, float &su, float &sv, float &sw) {
+    su = fmaf(RT_HALF(P.uz, h), d.z, fmaf(RT_HALF(P.uy, h), d.y, RT_HALF(P.ux, h) * d.x));
+    sv = fmaf(RT_HALF(P.vz, h), d.z, fmaf(RT_HALF(P.vy, h), d.y, RT_HALF(P.vx, h) * d.x));
+    sw = fmaf(RT_HALF(P.wz, h), d.z, fmaf(RT_HALF(P.wy, h), d.y, RT_HALF(P.wx, h) * d.x));
+}
+// camera rays (one-sided): acc = max(acc, min(u,v,w)) per triangle; may hit iff acc >= -theta
+DEV float filter_cam_pair(const PairCam &P, v2f Dx, v2f Dy, v2f Dz, float acc) {
+    v2f su, sv, sw;
+    edges_cam_pair(P, Dx, Dy, Dz, su, sv, sw);
+    return max3f(acc, min3f(su.x, sv.x, sw.x), min3f(su.y, sv.y, sw.y));
+}
+DEV float filter_cam_one(const PairCam &P, int h, f3 d) {
+    float su, sv, sw;
+    edges_cam_one(P, h, d, su, sv, sw);
+    return min3f(su, sv, sw);
+}
+// lines through a lamp (two-sided): acc = max(acc, max(min(u,v,w), -max(u,v,w)))
+DEV float filter_line_pair(const PairCam &P, v2f Dx, v2f Dy, v2f Dz, float acc) {
+    v2f su, sv, sw;
+    edges_cam_pair(P, Dx, Dy, Dz, su, sv, sw);
+    acc = max3f(acc, min3f(su.x, sv.x, sw.x), -max3f(su.x, sv.x, sw.x));
+    return max3f(acc, min3f(su.y, sv.y, sw.y), -max3f(su.y, sv.y, sw.y));
+}
+DEV float filter_line_one(const PairCam &P, int h, f3 d) {
+    float su, sv, sw;
+    edges_cam_one(P, h, d, su, sv, sw);
+    return fmaxf(min3f(su, sv, sw), -max3f(su, sv, sw));
 }
 
-// per-ray constants of the general FILTER
-struct RayF { f3 d, mo; float ro, rd; };
+// per-ray constants of the general FILTER: unit direction, moment about `center`, threshold
+struct RayF { v2f D[3], M[3]; f3 d, mo; float thr; };
 DEV RayF rayf_make(const DScene &S, f3 o, f3 d) {
     RayF r;
     f3 op = mk(o.x - S.center[0], o.y - S.center[1], o.z - S.center[2]);
-    r.d = d;
-    r.mo = cross(op, d);
-    r.rd = sqrtf(dot(d, d)) * 1.0001f;
-    r.ro = sqrtf(dot(op, op)) * r.rd;
+    float inv = 1.0f / sqrtf(dot(d, d));
+    r.d = d * inv;
+    r.mo = cross(op, r.d);
+    float far = sqrtf(dot(op, op)) / S.rmax;
+    r.thr = -(S.theta * fmaxf(1.0f, far));
+    if (!(r.thr > -3.0e38f) || !(inv < 3.0e38f) || !(inv > 0.f)) {   // degenerate ray: exact test decides
+        r.thr = -3.0e38f; r.d = mk(0.f, 0.f, 0.f); r.mo = mk(0.f, 0.f, 0.f);
+    }
+    r.D[0] = splat(r.d.x); r.D[1] = splat(r.d.y); r.D[2] = splat(r.d.z);
+    r.M[0] = splat(r.mo.x); r.M[1] = splat(r.mo.y); r.M[2] = splat(r.mo.z);
     return r;
 }
-// arbitrary ray vs general FILTER record (5 float4); true = may be a hit
-DEV bool filter_gen(const RayF &r, float4 f0, float4 f1, float4 f2, float4 f3_, float4 f4) {
-    float su = fmaf(f1.y, r.mo.z, fmaf(f1.x, r.mo.y, fmaf(f0.w, r.mo.x, dot3_fma(f0.x, f0.y, f0.z, r.d))));
-    float sv = fmaf(f2.w, r.mo.z, fmaf(f2.z, r.mo.y, fmaf(f2.y, r.mo.x, dot3_fma(f1.z, f1.w, f2.x, r.d))));
-    float sw = fmaf(f4.y, r.mo.z, fmaf(f4.x, r.mo.y, fmaf(f3_.w, r.mo.x, dot3_fma(f3_.x, f3_.y, f3_.z, r.d))));
-    float slack = fmaf(f4.z, r.ro, f4.w * r.rd);
-    float mn = fminf(fminf(su, sv), sw);
-    float mx = fmaxf(fmaxf(su, sv), sw);
-    return !(mn < -slack && mx > slack);
+// acc = max(acc, max(min(u,v,w), -max(u,v,w))) per triangle of the pair; may hit iff acc >= thr
+DEV float filter_gen_pair(const PairGen &P, const RayF &r, float acc) {
+    v2f su = pk_fma(P.um[2], r.M[2], pk_fma(P.um[1], r.M[1], pk_fma(P.um[0], r.M[0],
+             pk_fma(P.ud[2], r.D[2], pk_fma(P.ud[1], r.D[1], P.ud[0] * r.D[0])))));
+    v2f sv = pk_fma(P.vm[2], r.M[2], pk_fma(P.vm[1], r.M[1], pk_fma(P.vm[0], r.M[0],
+             pk_fma(P.vd[2], r.D[2], pk_fma(P.vd[1], r.D[1], P.vd[0] * r.D[0])))));
+    v2f sw = pk_fma(P.wm[2], r.M[2], pk_fma(P.wm[1], r.M[1], pk_fma(P.wm[0], r.M[0],
+             pk_fma(P.wd[2], r.D[2], pk_fma(P.wd[1], r.D[1], P.wd[0] * r.D[0])))));
+    acc = max3f(acc, min3f(su.x, sv.x, sw.x), -max3f(su.x, sv.x, sw.x));
+    return max3f(acc, min3f(su.y, sv.y, sw.y), -max3f(su.y, sv.y, sw.y));
+}
+DEV float filter_gen_one(const PairGen &P, int h, const RayF &r) {
+    float su = fmaf(RT_HALF(P.um[2], h), r.mo.z, fmaf(RT_HALF(P.um[1], h), r.mo.y, fmaf(RT_HALF(P.um[0], h), r.mo.x,
+               fmaf(RT_HALF(P.ud[2], h), r.d.z, fmaf(RT_HALF(P.ud[1], h), r.d.y, RT_HALF(P.ud[0], h) * r.d.x)))));
+    float sv = fmaf(RT_HALF(P.vm[2], h), r.mo.z, fmaf(RT_HALF(P.vm[1], h), r.mo.y, fmaf(RT_HALF(P.vm[0], h), r.mo.x,
+               fmaf(RT_HALF(P.vd[2], h), r.d.z, fmaf(RT_HALF(P.vd[1], h), r.d.y, RT_HALF(P.vd[0], h) * r.d.x)))));
+    float sw = fmaf(RT_HALF(P.wm[2], h), r.mo.z, fmaf(RT_HALF(P.wm[1], h), r.mo.y, fmaf(RT_HALF(P.wm[0], h), r.mo.x,
+               fmaf(RT_HALF(P.wd[2], h), r.d.z, fmaf(RT_HALF(P.wd[1], h), r.d.y, RT_HALF(P.wd[0], h) * r.d.x)))));
+    return fmaxf(min3f(su, sv, sw), -max3f(su, sv, sw));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -182,50 +286,59 @@ DEV void camera_rays(const DScene &S, const Frame &F, int x, int y, f3 *d) {
     }
 }
 
-template <int MODE, bool FILTER>
-__global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__restrict__ rays, float4 *__restrict__ hits)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__restrict__ rays, float4 *__restrict__ hits,
+                                                 unsigned long long *__restrict__ counters)
 {
+    uint32_t n_groups = 0;
     constexpr int SPP = (MODE == HIPEXEC_MODE_CL) ? 1 : 4;
-    constexpr int U = 4;
+    constexpr int UP = 2;                                   // triangle pairs per loop iteration
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     int x, y, lrow;
     bool active = slot_to_pixel(F, slot, x, y, lrow);
     if (!active) { x = min(x, F.W - 1); y = min(y, F.H - 1); }     // keep idle lanes on finite data
     f3 d[SPP];
     camera_rays<MODE>(S, F, x, y, d);
+    v2f Dx[SPP], Dy[SPP], Dz[SPP];
     Best tb[SPP];
 #pragma unroll
-    for (int r = 0; r < SPP; r++) tb[r] = best_none();
-
-    const float4 *__restrict__ FP = S.tri_fastp;
+    for (int r = 0; r < SPP; r++) { tb[r] = best_none(); Dx[r] = splat(d[r].x); Dy[r] = splat(d[r].y); Dz[r] = splat(d[r].z); }
+    const float thr = -S.theta;
+    const PairCam *__restrict__ PC = S.pair_cam;
     const float4 *__restrict__ PX = S.tri_primx;
-    for (uint32_t i = 0; i < S.n_tri_pad; i += U) {
-        bool any = !FILTER;
-        if (FILTER) {
+    const uint32_t n_pairs = S.n_tri_pad / 2;
+    for (uint32_t jp = 0; jp < n_pairs; jp += UP) {
+        float acc[SPP];
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                float4 a = FP[3 * (i + k)], b = FP[3 * (i + k) + 1], c = FP[3 * (i + k) + 2];
+        for (int r = 0; r < SPP; r++) acc[r] = -3.0e38f;
 #pragma unroll
-                for (int r = 0; r < SPP; r++) any |= filter_cam(d[r], a, b, c);
-            }
+        for (int k = 0; k < UP; k++) {
+            PairCam P = PC[jp + k];
+#pragma unroll
+            for (int r = 0; r < SPP; r++) acc[r] = filter_cam_pair(P, Dx[r], Dy[r], Dz[r], acc[r]);
         }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < SPP; r++) any |= !(acc[r] < thr);
         if (__ballot(any)) {
+            n_groups++;
 #pragma unroll 1
-            for (int k = 0; k < U; k++) {
-                uint32_t ti = i + k;
-                float4 a = FP[3 * ti], b = FP[3 * ti + 1], c = FP[3 * ti + 2];
+            for (uint32_t ti = 2 * jp; ti < 2 * (jp + UP); ti++) {
+                PairCam P = PC[ti >> 1];
+                int h = (int)(ti & 1u);
                 float4 e0 = PX[3 * ti], e1 = PX[3 * ti + 1], e2 = PX[3 * ti + 2];
 #pragma unroll
                 for (int r = 0; r < SPP; r++) {
-                    if (!FILTER || filter_cam(d[r], a, b, c)) {
+                    if (!(filter_cam_one(P, h, d[r]) < thr)) {
                         float t, u, v;
-                        if (tri_exact_cam<MODE>(d[r], xyz(e0), e0.w, xyz(e1), xyz(e2), t, u, v))
+                        if (ti < S.n_tri && tri_exact_cam<MODE>(d[r], xyz(e0), e0.w, xyz(e1), xyz(e2), t, u, v))
                             best_update<MODE>(tb[r], t, u, v, (int)ti);
                     }
                 }
             }
         }
     }
+    if ((threadIdx.x & 63u) == 0 && n_groups) atomicAdd(&counters[2], (unsigned long long)n_groups);
     f3 o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
 #pragma unroll
     for (int r = 0; r < SPP; r++) {
@@ -243,11 +356,12 @@ __global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__re
 // ---------------------------------------------------------------------------------------
 // k_closest: closest hit of n queued rays, R rays per lane
 // ---------------------------------------------------------------------------------------
-template <int MODE, int R, bool FILTER>
+template <int MODE, int R>
 __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restrict__ rays, uint32_t n,
-                                                 float4 *__restrict__ hits)
+                                                 float4 *__restrict__ hits, unsigned long long *__restrict__ counters)
 {
-    constexpr int U = 4;
+    uint32_t n_groups = 0;
+    constexpr int UP = 2;
     uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     uint32_t lane = threadIdx.x & 63u;
     uint32_t base = wave * 64u * R + lane;
@@ -261,30 +375,32 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
         rf[r] = rayf_make(S, o[r], d[r]);
         tb[r] = best_none();
     }
-    if (n == 0) return;
-    const float4 *__restrict__ FG = S.tri_fastg;
+    const PairGen *__restrict__ PG = S.pair_gen;
     const float4 *__restrict__ EX = S.tri_exact;
-    for (uint32_t i = 0; i < S.n_tri_pad; i += U) {
-        bool any = !FILTER;
-        if (FILTER) {
+    const uint32_t n_pairs = S.n_tri_pad / 2;
+    for (uint32_t jp = 0; jp < n_pairs; jp += UP) {
+        float acc[R];
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                const float4 *g = FG + 5 * (size_t)(i + k);
-                float4 f0 = g[0], f1 = g[1], f2 = g[2], f3_ = g[3], f4 = g[4];
+        for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
 #pragma unroll
-                for (int r = 0; r < R; r++) any |= filter_gen(rf[r], f0, f1, f2, f3_, f4);
-            }
+        for (int k = 0; k < UP; k++) {
+            PairGen P = PG[jp + k];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = filter_gen_pair(P, rf[r], acc[r]);
         }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) any |= !(acc[r] < rf[r].thr);
         if (__ballot(any)) {
+            n_groups++;
 #pragma unroll 1
-            for (int k = 0; k < U; k++) {
-                uint32_t ti = i + k;
-                const float4 *g = FG + 5 * (size_t)ti;
-                float4 f0 = g[0], f1 = g[1], f2 = g[2], f3_ = g[3], f4 = g[4];
+            for (uint32_t ti = 2 * jp; ti < 2 * (jp + UP); ti++) {
+                PairGen P = PG[ti >> 1];
+                int h = (int)(ti & 1u);
                 float4 e0 = EX[3 * ti], e1 = EX[3 * ti + 1], e2 = EX[3 * ti + 2];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    if (!FILTER || filter_gen(rf[r], f0, f1, f2, f3_, f4)) {
+                    if (!(filter_gen_one(P, h, rf[r]) < rf[r].thr)) {
                         float t, u, v;
                         if (ti < S.n_tri && tri_exact<MODE>(o[r], d[r], xyz(e0), xyz(e1), xyz(e2), t, u, v))
                             best_update<MODE>(tb[r], t, u, v, (int)ti);
@@ -293,6 +409,7 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
             }
         }
     }
+    if (lane == 0 && n_groups) atomicAdd(&counters[3], (unsigned long long)n_groups);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         Best sb = spheres_closest<MODE>(S, o[r], d[r]);
@@ -307,60 +424,209 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
 // triangles by index, then spheres; a scan stops at its first hit).
 // counters[0] += triangle tests, counters[1] += sphere tests.
 // ---------------------------------------------------------------------------------------
-template <int MODE, bool FILTER>
+template <int MODE, int R>
 __global__ __launch_bounds__(256) void k_anyhit(DScene S, const float4 *__restrict__ rays, uint32_t n,
                                                 uint32_t *__restrict__ occl, uint32_t lw,
                                                 unsigned long long *__restrict__ counters)
 {
-    constexpr int U = 4;
-    uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    bool valid = j < n;
-    f3 o, d; uint32_t s, lamp;
-    load_ray(rays, valid ? j : 0u, o, d, s, lamp);
-    RayF rf = rayf_make(S, o, d);
-    bool done = !valid;
-    uint32_t tri_tests = valid ? S.n_tri : 0u, sph_tests = valid ? S.n_sph : 0u;
-    bool occluded = false;
-    const float4 *__restrict__ FG = S.tri_fastg;
-    const float4 *__restrict__ EX = S.tri_exact;
-    for (uint32_t i = 0; i < S.n_tri_pad; i += U) {
-        if (__ballot(!done) == 0) break;
-        bool any = !FILTER && !done;
-        if (FILTER) {
+    constexpr int UP = 2;
+    uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = wave * 64u * R + lane;
+    uint32_t n_groups = 0;
+    f3 o[R], d[R]; RayF rf[R]; bool done[R], occluded[R]; uint32_t s[R], lamp[R], tri_tests[R], sph_tests[R];
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                const float4 *g = FG + 5 * (size_t)(i + k);
-                any |= filter_gen(rf, g[0], g[1], g[2], g[3], g[4]);
-            }
-            any = any && !done;
+    for (int r = 0; r < R; r++) {
+        uint32_t j = base + 64u * r;
+        bool valid = j < n;
+        load_ray(rays, valid ? j : 0u, o[r], d[r], s[r], lamp[r]);
+        rf[r] = rayf_make(S, o[r], d[r]);
+        done[r] = !valid; occluded[r] = false;
+        tri_tests[r] = valid ? S.n_tri : 0u; sph_tests[r] = valid ? S.n_sph : 0u;
+    }
+    const PairGen *__restrict__ PG = S.pair_gen;
+    const float4 *__restrict__ EX = S.tri_exact;
+    const uint32_t n_pairs = S.n_tri_pad / 2;
+    for (uint32_t jp = 0; jp < n_pairs; jp += UP) {
+        bool alive = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) alive |= !done[r];
+        if (__ballot(alive) == 0) break;
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < UP; k++) {
+            PairGen P = PG[jp + k];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = filter_gen_pair(P, rf[r], acc[r]);
         }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) any |= !(acc[r] < rf[r].thr) && !done[r];
         if (__ballot(any)) {
+            n_groups++;
 #pragma unroll 1
-            for (int k = 0; k < U; k++) {
-                uint32_t ti = i + k;
-                const float4 *g = FG + 5 * (size_t)ti;
+            for (uint32_t ti = 2 * jp; ti < 2 * (jp + UP); ti++) {
+                PairGen P = PG[ti >> 1];
+                int h = (int)(ti & 1u);
                 float4 e0 = EX[3 * ti], e1 = EX[3 * ti + 1], e2 = EX[3 * ti + 2];
-                if (!done && ti < S.n_tri && (!FILTER || filter_gen(rf, g[0], g[1], g[2], g[3], g[4]))) {
-                    float t, u, v;
-                    if (tri_exact<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), t, u, v)) {
-                        done = true; occluded = true; tri_tests = ti + 1; sph_tests = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (!done[r] && ti < S.n_tri && !(filter_gen_one(P, h, rf[r]) < rf[r].thr)) {
+                        float t, u, v;
+                        if (tri_exact<MODE>(o[r], d[r], xyz(e0), xyz(e1), xyz(e2), t, u, v)) {
+                            done[r] = true; occluded[r] = true; tri_tests[r] = ti + 1; sph_tests[r] = 0;
+                        }
                     }
                 }
             }
         }
     }
-    if (!done) {
-        for (uint32_t k = 0; k < S.n_sph; k++) {
-            float4 sp = S.sph[k];
-            float t;
-            if (!done && sph_exact<MODE>(o, d, xyz(sp), sp.w, t)) { done = true; occluded = true; sph_tests = k + 1; }
+    unsigned long long a = 0, b = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (!done[r]) {
+            for (uint32_t k = 0; k < S.n_sph; k++) {
+                float4 sp = S.sph[k];
+                float t;
+                if (!done[r] && sph_exact<MODE>(o[r], d[r], xyz(sp), sp.w, t)) { done[r] = true; occluded[r] = true; sph_tests[r] = k + 1; }
+            }
         }
+        if (occluded[r]) atomicOr(&occl[(size_t)s[r] * lw + (lamp[r] >> 5)], 1u << (lamp[r] & 31u));
+        a += tri_tests[r]; b += sph_tests[r];
     }
-    if (occluded) atomicOr(&occl[(size_t)s * lw + (lamp >> 5)], 1u << (lamp & 31u));
-    unsigned long long a = wave_sum_u64(tri_tests), b = wave_sum_u64(sph_tests);
-    if ((threadIdx.x & 63u) == 0) {
+    a = wave_sum_u64(a); b = wave_sum_u64(b);
+    if (lane == 0) {
         if (a) atomicAdd(&counters[0], a);
         if (b) atomicAdd(&counters[1], b);
+        if (n_groups) atomicAdd(&counters[4], (unsigned long long)n_groups);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_anyhit_lamp: the same occlusion query for shadow rays that all point at one lamp, with the
+// cheaper lamp-line FILTER (pair_lamp records of that lamp).  Exact tests and results are
+// those of k_anyhit.
+// ---------------------------------------------------------------------------------------
+// Triangle-pair records are staged through LDS in chunks of LDS_CHUNK pairs: the 4 waves of a
+// workgroup fetch each chunk from L2/HBM once (coalesced 16-byte loads, double buffered, next
+// chunk in flight during the tests of the current one) and read it back with uniform-address
+// ds_read_b128 broadcasts.
+constexpr int LDS_CHUNK = 64;
+
+template <int MODE, int R>
+__global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__restrict__ PL, const float4 *__restrict__ rays,
+                                                     uint32_t n, uint32_t *__restrict__ occl, uint32_t lw,
+                                                     unsigned long long *__restrict__ counters)
+{
+    constexpr int UP = 2;
+    constexpr int F4 = LDS_CHUNK * (int)(sizeof(PairCam) / 16);      // float4 per chunk (320)
+    __shared__ float4 lds[2][F4];
+    const uint32_t tid = threadIdx.x;
+    uint32_t wave = (blockIdx.x * 256u + tid) >> 6;
+    uint32_t lane = tid & 63u;
+    uint32_t base = wave * 64u * R + lane;
+    uint32_t n_groups = 0;
+    f3 o[R], d[R], dn[R]; v2f Dx[R], Dy[R], Dz[R];
+    bool done[R], occluded[R]; uint32_t s[R], lamp[R], tri_tests[R], sph_tests[R];
+    float thr[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint32_t j = base + 64u * r;
+        bool valid = j < n;
+        load_ray(rays, valid ? j : 0u, o[r], d[r], s[r], lamp[r]);
+        float inv = 1.0f / sqrtf(dot(d[r], d[r]));
+        dn[r] = d[r] * inv;
+        thr[r] = -S.theta;
+        if (!(inv < 3.0e38f) || !(inv > 0.f) || !(thr[r] > -3.0e38f)) { dn[r] = mk(0.f, 0.f, 0.f); thr[r] = -3.0e38f; }
+        Dx[r] = splat(dn[r].x); Dy[r] = splat(dn[r].y); Dz[r] = splat(dn[r].z);
+        done[r] = !valid; occluded[r] = false;
+        tri_tests[r] = valid ? S.n_tri : 0u; sph_tests[r] = valid ? S.n_sph : 0u;
+    }
+    const float4 *__restrict__ EX = S.tri_exact;
+    const float4 *__restrict__ G = reinterpret_cast<const float4 *>(PL);
+    const uint32_t n_chunks = (S.n_tri_pad / 2) / LDS_CHUNK;
+    if (n_chunks) {
+        lds[0][tid] = G[tid];
+        if (tid < F4 - 256) lds[0][256 + tid] = G[256 + tid];
+    }
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        const int buf = (int)(c & 1u);
+        float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;
+        const bool more = c + 1 < n_chunks;
+        if (more) {
+            const float4 *g = G + (size_t)(c + 1) * F4;
+            pre0 = g[tid];
+            if (tid < F4 - 256) pre1 = g[256 + tid];
+        }
+        bool alive = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) alive |= !done[r];
+        if (__ballot(alive)) {
+            const PairCam *L = reinterpret_cast<const PairCam *>(&lds[buf][0]);
+            for (uint32_t jl = 0; jl < LDS_CHUNK; jl += UP) {
+                float acc[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
+#pragma unroll
+                for (int k = 0; k < UP; k++) {
+                    PairCam P = L[jl + k];
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r] = filter_line_pair(P, Dx[r], Dy[r], Dz[r], acc[r]);
+                }
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < R; r++) any |= !(acc[r] < thr[r]) && !done[r];
+                if (__ballot(any)) {
+                    n_groups++;
+#pragma unroll 1
+                    for (uint32_t tl = 2 * jl; tl < 2 * (jl + UP); tl++) {
+                        uint32_t ti = 2 * c * LDS_CHUNK + tl;
+                        PairCam P = L[tl >> 1];
+                        int h = (int)(tl & 1u);
+                        float4 e0 = EX[3 * ti], e1 = EX[3 * ti + 1], e2 = EX[3 * ti + 2];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            if (!done[r] && ti < S.n_tri && !(filter_line_one(P, h, dn[r]) < thr[r])) {
+                                float t, u, v;
+                                if (tri_exact<MODE>(o[r], d[r], xyz(e0), xyz(e1), xyz(e2), t, u, v)) {
+                                    done[r] = true; occluded[r] = true; tri_tests[r] = ti + 1; sph_tests[r] = 0;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        alive = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) alive |= !done[r];
+        if (more) {
+            lds[buf ^ 1][tid] = pre0;
+            if (tid < F4 - 256) lds[buf ^ 1][256 + tid] = pre1;
+        }
+        if (!__syncthreads_or(alive ? 1 : 0)) break;
+    }
+    unsigned long long a = 0, b = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (!done[r]) {
+            for (uint32_t k = 0; k < S.n_sph; k++) {
+                float4 sp = S.sph[k];
+                float t;
+                if (!done[r] && sph_exact<MODE>(o[r], d[r], xyz(sp), sp.w, t)) { done[r] = true; occluded[r] = true; sph_tests[r] = k + 1; }
+            }
+        }
+        if (occluded[r]) atomicOr(&occl[(size_t)s[r] * lw + (lamp[r] >> 5)], 1u << (lamp[r] & 31u));
+        a += tri_tests[r]; b += sph_tests[r];
+    }
+    a = wave_sum_u64(a); b = wave_sum_u64(b);
+    if (lane == 0) {
+        if (a) atomicAdd(&counters[0], a);
+        if (b) atomicAdd(&counters[1], b);
+        if (n_groups) atomicAdd(&counters[4], (unsigned long long)n_groups);
     }
 }
 
@@ -371,6 +637,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_shadowgen(DScene S, const float4 *__restrict__ rays, const float4 *__restrict__ hits,
                                                    uint32_t n, float4 *__restrict__ shadow_q, uint32_t *__restrict__ q_count)
 {
+    // queue of lamp l: records [l*n, l*n + q_count[l])
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
@@ -386,8 +653,8 @@ __global__ __launch_bounds__(256) void k_shadowgen(DScene S, const float4 *__res
         float dotWithLamp = dot(toLamp, sf.N);
         float dotWithDir = dot(d, sf.N);
         bool cast = hit && casts_shadow_ray<MODE>(dotWithDir, dotWithLamp);
-        uint32_t pos = wave_append(cast, q_count);
-        if (cast) store_ray(shadow_q, pos, sf.P, toLamp, s, l);
+        uint32_t pos = wave_append(cast, q_count + l);
+        if (cast) store_ray(shadow_q + 2 * (size_t)l * n, pos, sf.P, toLamp, s, l);
     }
 }
 
