@@ -75,17 +75,17 @@ class FlatScene:
 
     # ------------------------------------------------------------------------------------
     @property
-    def n_tri(self): return int(self.tri_p.shape[0])
+    def n_tri(self): return int(np.size(self.tri_p) // 3)
 
     @property
-    def n_sph(self): return int(self.sph_center.shape[0])
+    def n_sph(self): return int(np.size(self.sph_radius))
 
     @property
-    def n_lamp(self): return int(self.lamp_pos.shape[0])
+    def n_lamp(self): return int(np.size(self.lamp_intensity))
 
     def normalised(self) -> "FlatScene":
         """Coerce dtypes/shapes/contiguity in place and return self."""
-        n = self.tri_p.shape[0] if np.ndim(self.tri_p) == 2 else len(self.tri_p) // 3
+        n = np.size(np.asarray(self.tri_p, dtype=np.float32)) // 3
         self.tri_p = _f32(self.tri_p, (n, 3)); self.tri_e1 = _f32(self.tri_e1, (n, 3))
         self.tri_e2 = _f32(self.tri_e2, (n, 3)); self.tri_norm = _f32(self.tri_norm, (n, 3))
         if self.tri_uv is None or np.size(self.tri_uv) == 0:

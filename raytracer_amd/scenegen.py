@@ -269,7 +269,7 @@ def scene_mirror_box(seed=7) -> SceneSpec:
             material((0.9, 0.3, 0.2), kd=0.7, ks=0.9, hard=90, kr=0.4),
             material(rng.uniform(0.2, 0.9, 3), kd=0.7, ks=0.5, hard=30, kr=0.0)]
     sph = [{"center": [-1, 1, -6], "radius": 1.0, "material": 1}, {"center": [2, 2, -8], "radius": 1.25, "material": 2}]
-    lamps = [{"pos": [0, 5, -3], "intensity": 1.0, "distance": 12.0}, {"pos": [-3, 4, -9], "intensity": 0.7, "distance": 10.0}]
+    lamps = [{"pos": [0, 5, -3], "intensity": 1.0, "distance": 45.0}, {"pos": [-3, 4, -9], "intensity": 0.7, "distance": 35.0}]
     T, pos = camera((0, 3, 1), pitch_deg=-8, yaw_deg=4)
     return SceneSpec(bv, bf, None, None, np.zeros((bf.shape[0],), np.int32), mats, sph, lamps, T, pos,
                      {"ambientColor": [0.02, 0.02, 0.02], "horizonColor": [0.3, 0.3, 0.3], "ambientFactor": 0.0})

@@ -1,0 +1,258 @@
+"""Known-answer tests of the CPU oracle (oracle/rt_oracle.c).
+
+The reference ships no tests or vectors, so these answers are derived by hand from its
+sources (file:line cited per case).  They pin the oracle's thresholds, edge rules, tie rules
+and documented quirks; they are not outputs of the reference itself (parity unpinned).
+"""
+import numpy as np
+import pytest
+
+from raytracer_amd import _abi
+from raytracer_amd.scene import FlatScene
+from oracle import binding as orc
+
+CPU, CL = _abi.HIPEXEC_MODE_CPU, _abi.HIPEXEC_MODE_CL
+f32 = np.float32
+P, E1, E2 = [0, 0, 0], [1, 0, 0], [0, 1, 0]          # unit right triangle in z = 0, u along x, v along y
+
+
+def tri(mode, o, d):
+    return orc.triangle_hit(mode, P, E1, E2, o, d)
+
+
+def test_triangle_centre_hit():
+    for mode in (CPU, CL):
+        hit, t, u, v, pt = tri(mode, [0.25, 0.25, 1], [0, 0, -1])
+        assert hit and t == 1 and u == f32(0.25) and v == f32(0.25)
+        assert np.array_equal(pt, np.array([0.25, 0.25, 0], f32))
+
+
+def test_triangle_unnormalised_direction_scales_t_only():
+    hit, t, u, v, _ = tri(CPU, [0.25, 0.5, 2], [0, 0, -4])
+    assert hit and t == f32(0.5) and u == f32(0.25) and v == f32(0.5)
+
+
+@pytest.mark.parametrize("o,cpu_hit", [([0.0, 0.25, 1], True),      # u == 0
+                                       ([0.25, 0.0, 1], True),      # v == 0
+                                       ([0.5, 0.5, 1], True),       # u + v == 1
+                                       ([0.0, 0.0, 1], True),       # vertex
+                                       ([0.75, 0.5, 1], False),     # u + v > 1
+                                       ([-0.01, 0.2, 1], False)])   # u < 0
+def test_triangle_edges_inclusive_cpu_strict_cl(o, cpu_hit):
+    # ray_tracer.cpp:323 rejects u<0 || v<0 || u+v>1 (edges inclusive); cl_kernels.c:147 needs u>0 && v>0 && u+v<1
+    assert tri(CPU, o, [0, 0, -1])[0] == cpu_hit
+    assert tri(CL, o, [0, 0, -1])[0] is False
+
+
+def test_triangle_behind_and_parallel():
+    for mode in (CPU, CL):
+        assert not tri(mode, [0.25, 0.25, 1], [0, 0, 1])[0]        # t = -1
+        assert not tri(mode, [0.25, 0.25, 1], [1, 0, 0])[0]        # det = 0
+
+
+def test_triangle_t_threshold():
+    eps_f = f32(0.0001)                                            # largest float below 1e-4
+    up = np.nextafter(eps_f, f32(1))
+    # ray_tracer.cpp:315  t < EPS (double compare): t = 0.0001f is rejected, the next float is accepted
+    assert not tri(CPU, [0.25, 0.25, eps_f], [0, 0, -1])[0]
+    assert tri(CPU, [0.25, 0.25, up], [0, 0, -1])[0]
+    # cl_kernels.c:146  t > 0.001f
+    assert not tri(CL, [0.25, 0.25, f32(0.001)], [0, 0, -1])[0]
+    assert tri(CL, [0.25, 0.25, np.nextafter(f32(0.001), f32(1))], [0, 0, -1])[0]
+
+
+def test_triangle_det_threshold():
+    eps_f = f32(0.0001)
+    up = np.nextafter(eps_f, f32(1))
+    # ray_tracer.cpp:309  fabsf(det) < EPS; det = -d.z here
+    assert not tri(CPU, [0.25, 0.25, 1], [0, 0, -eps_f])[0]
+    hit, t, u, v, _ = tri(CPU, [0.25, 0.25, 1], [0, 0, -up])
+    assert hit and t == f32(1) / up
+    # cl_kernels.c:145  det > 0.001f || det < -0.001f
+    assert not tri(CL, [0.25, 0.25, 1], [0, 0, -f32(0.001)])[0]
+    assert tri(CL, [0.25, 0.25, 1], [0, 0, -np.nextafter(f32(0.001), f32(1))])[0]
+
+
+def test_triangle_back_face_hits_too():
+    hit, t, u, v, _ = tri(CPU, [0.25, 0.25, -2], [0, 0, 1])        # det < 0: no culling in the reference
+    assert hit and t == 2 and u == f32(0.25) and v == f32(0.25)
+
+
+def test_sphere_two_roots_and_inside():
+    for mode in (CPU, CL):
+        hit, t, pt, n = orc.sphere_hit(mode, [0, 0, 0], 1.0, [0, 0, 3], [0, 0, -1])
+        assert hit and t == 2 and np.array_equal(pt, [0, 0, 1]) and np.array_equal(n, [0, 0, 1])
+        hit, t, pt, n = orc.sphere_hit(mode, [0, 0, 0], 1.0, [0, 0, 0], [0, 0, -1])     # origin inside: far root
+        assert hit and t == 1 and np.array_equal(pt, [0, 0, -1])
+        assert not orc.sphere_hit(mode, [0, 0, 0], 1.0, [2, 0, 3], [0, 0, -1])[0]
+        assert not orc.sphere_hit(mode, [0, 0, 0], 1.0, [0, 0, 3], [0, 0, 1])[0]        # both roots negative
+
+
+def test_sphere_unnormalised_direction():
+    hit, t, pt, n = orc.sphere_hit(CPU, [0, 0, 0], 1.0, [0, 0, 3], [0, 0, -2])          # a = 4
+    assert hit and t == 1 and np.array_equal(pt, [0, 0, 1])
+
+
+def test_sphere_normal_is_divided_by_radius():
+    hit, t, pt, n = orc.sphere_hit(CPU, [0, 0, 0], 2.0, [0, 0, 5], [0, 0, -1])
+    assert hit and t == 3 and np.array_equal(n, [0, 0, 1])
+
+
+def test_sphere_tangent_branch_quirk():
+    # D == 0.  ray_tracer.cpp:345-347 takes t = -b/2*a (multiplies by a): exact for a = 1 ...
+    hit, t, _, _ = orc.sphere_hit(CPU, [0, 0, 0], 1.0, [1, 0, 3], [0, 0, -1])
+    assert hit and t == 3
+    # ... and 4x too large for |d| = 2 (true t is 1.5): b = -12, a = 4 -> (12/2)*4 = 24
+    hit, t, _, _ = orc.sphere_hit(CPU, [0, 0, 0], 1.0, [1, 0, 3], [0, 0, -2])
+    assert hit and t == 24
+    # cl_kernels.c:214 needs D > -0.0 for that branch, so D == 0 goes through sqrt: t = 12/8
+    hit, t, _, _ = orc.sphere_hit(CL, [0, 0, 0], 1.0, [1, 0, 3], [0, 0, -2])
+    assert hit and t == f32(1.5)
+
+
+def _scene(tris, spheres=(), mats=1, lamps=()):
+    s = FlatScene()
+    s.tri_p = [t[0] for t in tris]; s.tri_e1 = [t[1] for t in tris]; s.tri_e2 = [t[2] for t in tris]
+    s.tri_norm = [[0, 0, 1]] * len(tris); s.tri_mat = [t[3] for t in tris]
+    s.sph_center = [sp[0] for sp in spheres]; s.sph_radius = [sp[1] for sp in spheres]; s.sph_mat = [sp[2] for sp in spheres]
+    s.mat_color = [[0.1 * (i + 1), 0.2, 0.3] for i in range(mats)]
+    s.mat_kd = [0.5] * mats; s.mat_ks = [0.25] * mats; s.mat_hard = [2.0] * mats; s.mat_kr = [0.0] * mats
+    s.mat_tex = [-1] * mats
+    s.lamp_pos = [l[0] for l in lamps]; s.lamp_intensity = [l[1] for l in lamps]; s.lamp_distance = [l[2] for l in lamps]
+    return s.normalised()
+
+
+BIG = ([-10, -10, 0], [20, 0, 0], [0, 20, 0])
+
+
+def test_closest_lowest_index_wins_ties():
+    # ray_tracer.cpp:214 / opencl_executor.cpp:242: strict '<' keeps the first of equal t
+    s = _scene([(*BIG, 0), (*BIG, 1), ([-10, -10, -1], [20, 0, 0], [0, 20, 0], 1)], mats=2)
+    o = orc.Oracle(s)
+    for mode in (CPU, CL):
+        h = o.closest_hits([[-0.5, -0.25, 3, 0, 0, -1]], mode)[0]
+        assert h["id"] == 0 and h["mat"] == 0 and h["t"] == 3
+        assert np.array_equal(h["color"], s.mat_color[0])
+
+
+def test_sphere_triangle_tie_rule_differs_by_mode():
+    # sphere of radius 1 centred at z = -1 touches the plane z = 0 at the origin: both t = 3
+    s = _scene([(*BIG, 0)], spheres=[([-1, -1, -1], 1.0, 1)], mats=2)
+    o = orc.Oracle(s)
+    assert o.closest_hits([[-1, -1, 3, 0, 0, -1]], CPU)[0]["id"] == 1      # ray_tracer.cpp:230: sphere wins
+    assert o.closest_hits([[-1, -1, 3, 0, 0, -1]], CL)[0]["id"] == 0       # ray_tracer_cl.cpp:206: triangle wins
+
+
+def test_null_material_is_default_black():
+    s = _scene([(*BIG, -1)], mats=1)
+    h = orc.Oracle(s).closest_hits([[-0.5, -0.5, 1, 0, 0, -1]], CPU)[0]
+    assert h["id"] == 0 and h["mat"] == -1 and np.array_equal(h["color"], [0, 0, 0])
+
+
+def test_any_hit_is_unbounded_and_counts_reference_order():
+    # occluder beyond the "lamp" still shadows: ray_tracer.cpp:282-294 has no upper bound on t
+    s = _scene([([5, 5, 50], [1, 0, 0], [0, 1, 0], 0), (*BIG, 0)], spheres=[([-0.5, -0.5, 30], 1.0, 0)])
+    o = orc.Oracle(s)
+    st = _abi.Stats()
+    rays = [[-0.5, -0.5, 1, 0, 0, 1],    # misses tri 0, misses tri 1 (behind), hits the sphere at z=29
+            [-0.5, -0.5, -1, 0, 0, 1],   # hits tri 1 (index 1) first in scan order
+            [100, 100, 1, 0, 0, 1]]      # hits nothing
+    hits = o.any_hits(rays, CPU, stats=st)
+    assert list(hits) == [1, 1, 0]
+    assert st.rays_shadow == 3
+    assert st.tests_tri_any == 2 + 2 + 2 and st.tests_sph_any == 1 + 0 + 1
+    pre = np.array([0, 0, 1], np.int8)   # OR-ed into the caller's array (ray_tracer_cl.cpp:255,260)
+    assert list(o.any_hits(rays, CL, hits=pre)) == [1, 1, 1]
+
+
+def test_texture_fetch_flip_wrap_and_float_to_unsigned():
+    s = _scene([(*BIG, 0)], mats=1)
+    tex = np.zeros((4, 4, 4), np.uint8)
+    for r in range(4):
+        for c in range(4):
+            tex[r, c] = (10 * r, 10 * c, 7, 255)
+    s.textures = [tex]; s.mat_tex = [0]
+    s.tri_uv = [[0, 0, 20, 0, 0, 20]]            # uv = (20*(u), 20*(v)) texel units
+    o = orc.Oracle(s.normalised())
+    # tex_image.h:37: row (H-1-y), column x of the top-down image
+    assert np.array_equal(o.tex_get(0, 1, 0) * 255, [30, 10, 7, 255])
+    assert np.array_equal(o.tex_get(0, 2, 3) * 255, [0, 20, 7, 255])
+    assert np.array_equal(o.tex_get(0, 5, 6) * 255, [10, 10, 7, 255])       # wrap: x=5%4=1, y=6%4=2 -> row 1
+    # (unsigned) of a negative float as x86-64 evaluates it: -3.7 -> 0xFFFFFFFD -> % 4 = 1
+    assert np.array_equal(o.tex_get(0, 0xFFFFFFFD, 0) * 255, [30, 10, 7, 255])
+
+
+def test_trace_cpu_single_lamp_hand_computed():
+    """One lit point, colour evaluated by hand in float32 in the reference's order (ray_tracer.cpp:166-187)."""
+    s = _scene([(*BIG, 0)], mats=1, lamps=[([-1, -1, 4], 2.0, 3.0)])
+    s.ambient = [0.01, 0.02, 0.03]; s.horizon = [0.5, 0.5, 0.5]
+    o = orc.Oracle(s.normalised())
+    d = np.array([0, 0, -1], f32)
+    col = o.trace_rays([[-1, -1, 2, *d]], CPU, max_depth=0)[0]
+    color = np.array(s.mat_color[0], f32)
+    toLamp = np.array([0, 0, 4], f32)
+    diff = f32(2.0) * f32(3.0) * f32(4.0) / f32(16.0)                       # I*dist*|N.L| / L.L
+    exp = np.array(s.ambient, f32) + (color * f32(0.5)) * diff
+    refl = toLamp - (f32(2.0) * np.array([0, 0, 1], f32)) * f32(4.0)        # (0,0,-4) -> normalised (0,0,-1)
+    refl = refl * (f32(1.0) / np.sqrt(f32(16.0)))
+    sd = f32(refl @ d)                                                      # 1
+    phong = (f32(2.0) * f32(3.0) / f32(16.0)) * f32(np.power(sd, f32(2.0)))
+    exp = exp + (color * f32(0.25)) * phong
+    assert np.array_equal(col, exp.astype(f32))
+    # a miss returns the horizon colour (ray_tracer.cpp:199)
+    assert np.array_equal(o.trace_rays([[100, 100, 2, 0, 0, -1]], CPU)[0], [0.5, 0.5, 0.5])
+
+
+def test_trace_facing_rules_differ_by_mode():
+    # lamp exactly in the plane of the triangle: dotWithLamp == 0.
+    s = _scene([(*BIG, 0)], mats=1, lamps=[([5, 0, 0], 1.0, 10.0)])
+    o = orc.Oracle(s)
+    st_cpu, st_cl = _abi.Stats(), _abi.Stats()
+    o.trace_rays([[-1, -1, 2, 0, 0, -1]], CPU, stats=st_cpu)
+    o.trace_rays([[-1, -1, 2, 0, 0, -1]], CL, stats=st_cl)
+    # ray_tracer.cpp:176 skips only equal strict signs -> a shadow ray is cast; ray_tracer_cl.cpp:143
+    # (dir<0 && lamp>=0) also casts one
+    assert st_cpu.rays_shadow == 1 and st_cl.rays_shadow == 1
+    # ray direction parallel to the surface normal plane (dotWithDir == 0): CPU casts, CL never lights
+    s2 = _scene([(*BIG, 0)], spheres=[([0, 0, 1], 1.0, 0)], mats=1, lamps=[([0, 0, 9], 1.0, 10.0)])
+    o2 = orc.Oracle(s2)
+    st_cpu, st_cl = _abi.Stats(), _abi.Stats()
+    ray = [[-5, 0, 2, 1, 0, 0]]       # grazes the sphere top at (0,0,2): normal (0,0,1), d.N == 0
+    o2.trace_rays(ray, CPU, stats=st_cpu); o2.trace_rays(ray, CL, stats=st_cl)
+    assert st_cpu.rays_shadow == 1 and st_cl.rays_shadow == 0
+
+
+def test_reflection_recursion_depth_and_threshold():
+    # two facing mirrors (kr = 0.5): depth-limited recursion, ray_tracer.cpp:191-195
+    s = _scene([([-10, -10, 0], [20, 0, 0], [0, 20, 0], 0), ([-10, -10, 4], [20, 0, 0], [0, 20, 0], 0)], mats=1)
+    s.mat_kr = [0.5]; s.ambient = [0.25, 0.25, 0.25]
+    o = orc.Oracle(s.normalised())
+    for depth in range(0, 5):
+        st = _abi.Stats()
+        c = o.trace_rays([[-1, -1, 2, 0, 0, -1]], CPU, max_depth=depth, stats=st)[0]
+        assert st.rays_primary == 1 and st.rays_bounce == depth
+        exp = f32(0)
+        for _ in range(depth + 1):
+            exp = f32(0.25) + exp * f32(0.5)
+        assert np.array_equal(c, [exp] * 3)
+    s.mat_kr = [0.0001]                      # kr > EPS is false for 0.0001f (config.h:20 is a double)
+    st = _abi.Stats()
+    orc.Oracle(s.normalised()).trace_rays([[-1, -1, 2, 0, 0, -1]], CPU, max_depth=3, stats=st)
+    assert st.rays_bounce == 0
+
+
+def test_render_region_matches_full_frame_and_threads():
+    from raytracer_amd import scenegen
+    fs = scenegen.small_variant("c2").to_flat()
+    o = orc.Oracle(fs)
+    full = o.render(40, 24, max_depth=2, n_threads=1)
+    par = o.render(40, 24, max_depth=2, n_threads=4)
+    assert np.array_equal(full["rgb"].view(np.int32), par["rgb"].view(np.int32))
+    assert np.array_equal(full["ids"], par["ids"]) and full["stats"].rays == par["stats"].rays
+    sub = o.render_region(40, 24, 8, 16, 24, 8, max_depth=2)         # like renderScene(..., x, y), ray_tracer.cpp:15-23
+    assert np.array_equal(sub["rgb"].view(np.int32), full["rgb"][16:24, 8:32].view(np.int32))
+    assert np.array_equal(sub["ids"], full["ids"][16:24, 8:32])
+    # pixel = sum of 4 sub-samples / 4 then powf(c/2.2, 0.3) (ray_tracer.cpp:42-51)
+    lin = full["linear"]
+    tone = np.power((lin / f32(2.2)).astype(np.float64), 0.3).astype(f32)
+    assert np.max(np.abs(tone - full["rgb"])) <= 2e-7
