@@ -1,0 +1,158 @@
+// ray_tracer_hip.cpp — drop-in replacement of the reference's ray_tracer_cl.cpp.
+//
+// Defines the five functions declared in the reference's ray_tracer_cl.h (unchanged) on top
+// of the C-ABI hip_executor library, so main.cpp, scene.cpp, the GLFW display and the texture
+// loading stay as they are.  `class OpenClExecutor` is only forward-declared for callers
+// (scene.h:19), so this file supplies its own definition: an RAII owner of a hipexec_t.
+//
+// Build inside the reference tree: replace ray_tracer_cl.cpp and
+// opencl_executor.cpp by this file in CMakeLists.txt:26-30 and link libhip_executor.so
+// instead of OpenCL.  The unit test of this repository compiles the same file against a
+// stand-in for the reference's types by defining RT_HIP_REFERENCE_HEADER.
+#ifdef RT_HIP_REFERENCE_HEADER
+#include RT_HIP_REFERENCE_HEADER
+#else
+#include "ray_tracer_cl.h"
+#endif
+
+#include <cmath>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "hip_executor.h"
+#include "scene_flatten.hpp"
+
+// Error convention of the reference's executor: message on std::cerr, then
+// std::runtime_error (opencl_executor.h:67-72).
+static void checkHipResult(int rc, const char *what)
+{
+    if (rc != HIPEXEC_OK) {
+        std::cerr << what << ": " << rc << " (" << hipexec_last_error() << ")" << std::endl;
+        throw std::runtime_error("hip_executor function failed");
+    }
+}
+
+class OpenClExecutor {
+public:
+    explicit OpenClExecutor(const Scene &scene) : flat_(scene)
+    {
+        checkHipResult(hipexec_create(&handle_, &flat_.desc(), -1), "hipexec_create");
+    }
+    ~OpenClExecutor() { hipexec_destroy(handle_); }
+    OpenClExecutor(const OpenClExecutor &) = delete;
+    OpenClExecutor &operator=(const OpenClExecutor &) = delete;
+    hipexec_t *handle() const { return handle_; }
+
+private:
+    rt_hip::FlatScene<Scene> flat_;
+    hipexec_t *handle_ = nullptr;
+};
+
+// ray_tracer_cl.cpp:9-56.  The reference walks the frame in 48x48 blocks only to bound its
+// dense result matrix; the executor renders the whole frame in one call with the same per-pixel
+// arithmetic (1 sample per pixel, tone curve), straight into the image_bitmap's float RGB rows.
+void renderSceneCl(image_bitmap &outImg, const Scene &scene)
+{
+    std::shared_ptr<OpenClExecutor> clExecutor(new OpenClExecutor(scene));
+    hipexec_render_cfg cfg{};
+    cfg.width = outImg.getWidth(); cfg.height = outImg.getHeight();
+    cfg.mode = HIPEXEC_MODE_CL; cfg.max_depth = 0; cfg.tone = 1;
+    cfg.tile_first = 0; cfg.tile_step = 1; cfg.flags = 0;
+    checkHipResult(hipexec_render(clExecutor->handle(), &cfg, static_cast<float *>(outImg.getRawData()), nullptr, nullptr),
+                   "hipexec_render");
+}
+
+// ray_tracer_cl.cpp:59-105: rays of one sub-block are generated here exactly as the reference
+// does (so a caller that renders block-wise gets the same pixels), traced as a batch, toned.
+void renderSubBlockCl(image_bitmap &outImg, const Scene &scene, std::shared_ptr<OpenClExecutor> clExecutor,
+                      int x, int y, int w, int h, int fullWidth, int fullHeight)
+{
+    auto width = fullWidth;
+    auto height = fullHeight;
+    float camHeight = 0.5;
+    float camWidth = static_cast<float>(width) * (camHeight / static_cast<float>(height));
+    float camDist = 1.0;
+    float dh = camHeight / static_cast<float>(height);
+    float dw = camWidth / static_cast<float>(width);
+    std::vector<glm::vec3> tracedColors;
+    std::vector<RayData> raysToTrace;
+    tracedColors.reserve((unsigned long)(w * h));
+    raysToTrace.reserve((unsigned long)(w * h));
+    for (int i = 0; i < h; i++) {
+        for (int j = 0; j < w; j++) {
+            float rayX = -(camWidth / 2) + (j + x) * dw;
+            float rayY = -(camHeight / 2) + (i + y) * dh;
+            glm::vec3 rayCamDir = glm::vec3(rayX, rayY, -camDist);
+            glm::vec3 rayWorldDir = glm::normalize(rayCamDir * scene.camMat);
+            tracedColors.push_back(glm::vec3(0.0f, 0.0f, 0.0f));
+            raysToTrace.push_back(RayData(scene.camPos.x, scene.camPos.y, scene.camPos.z,
+                                          rayWorldDir.x, rayWorldDir.y, rayWorldDir.z));
+        }
+    }
+    traceRaysCl(scene, clExecutor, raysToTrace, tracedColors, 0);
+    int k = 0;
+    for (int i = 0; i < h; i++) {
+        for (int j = 0; j < w; j++) {
+            outImg.setPixel(j + x, i + y, powf(tracedColors[k].x / 2.2f, 0.3f), powf(tracedColors[k].y / 2.2f, 0.3f),
+                            powf(tracedColors[k].z / 2.2f, 0.3f));
+            k++;
+        }
+    }
+}
+
+// ray_tracer_cl.cpp:108-178: outColors[i] is accumulated into; depth is accepted and ignored (:114)
+void traceRaysCl(const Scene &scene, std::shared_ptr<OpenClExecutor> clExecutor, const std::vector<RayData> &rays,
+                 std::vector<glm::vec3> &outColors, int depth)
+{
+    (void)scene; (void)depth;
+    if (rays.empty()) return;
+    static_assert(sizeof(RayData) == 6 * sizeof(float), "RayData must pack 6 floats (scene.h:156-169)");
+    std::vector<float> colours(3 * rays.size());
+    for (size_t i = 0; i < rays.size(); i++) { colours[3 * i] = outColors[i].x; colours[3 * i + 1] = outColors[i].y; colours[3 * i + 2] = outColors[i].z; }
+    checkHipResult(hipexec_trace_rays(clExecutor->handle(), HIPEXEC_MODE_CL, 0, reinterpret_cast<const float *>(rays.data()),
+                                      (uint32_t)rays.size(), colours.data(), nullptr), "hipexec_trace_rays");
+    for (size_t i = 0; i < rays.size(); i++) outColors[i] = glm::vec3(colours[3 * i], colours[3 * i + 1], colours[3 * i + 2]);
+}
+
+// ray_tracer_cl.cpp:181-242: hits is cleared and resized; misses keep Hit(false)
+void computeClosestHitsCl(const Scene &scene, std::shared_ptr<OpenClExecutor> clExecutor, const std::vector<RayData> &rays,
+                          std::vector<Hit> &hits)
+{
+    hits.clear();
+    hits.resize(rays.size(), Hit(false));
+    if (rays.empty()) return;
+    std::vector<hipexec_hit> out(rays.size());
+    checkHipResult(hipexec_closest_hits(clExecutor->handle(), HIPEXEC_MODE_CL, reinterpret_cast<const float *>(rays.data()),
+                                        (uint32_t)rays.size(), out.data()), "hipexec_closest_hits");
+    const size_t nTri = scene.triangles.size();
+    for (size_t i = 0; i < rays.size(); i++) {
+        const hipexec_hit &h = out[i];
+        if (h.id < 0) continue;
+        hits[i].isHit = true;
+        hits[i].mtl = ((size_t)h.id < nTri) ? scene.triangles[(size_t)h.id]->material : scene.spheres[(size_t)h.id - nTri]->material;
+        hits[i].point = glm::vec3(h.point[0], h.point[1], h.point[2]);
+        hits[i].norm = glm::vec3(h.norm[0], h.norm[1], h.norm[2]);
+        hits[i].color = glm::vec3(h.color[0], h.color[1], h.color[2]);
+        hits[i].t = h.t;
+    }
+}
+
+// ray_tracer_cl.cpp:245-262: hits[i] = hits[i] || occluded
+void computeAnyHitsCl(const Scene &scene, std::shared_ptr<OpenClExecutor> clExecutor, const std::vector<RayData> &rays,
+                      char *hits)
+{
+    (void)scene;
+    if (rays.empty()) return;
+    checkHipResult(hipexec_any_hits(clExecutor->handle(), HIPEXEC_MODE_CL, reinterpret_cast<const float *>(rays.data()),
+                                    (uint32_t)rays.size(), hits), "hipexec_any_hits");
+}
+
+#ifdef RT_HIP_REFERENCE_HEADER
+// test hook: the reference constructs executors only inside renderSceneCl (ray_tracer_cl.cpp:14)
+std::shared_ptr<OpenClExecutor> makeExecutorForTest(const Scene &scene)
+{
+    return std::shared_ptr<OpenClExecutor>(new OpenClExecutor(scene));
+}
+#endif

@@ -71,7 +71,8 @@ struct hipexec {
     Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
     uint32_t *d_cnt32 = nullptr;              // [0] next-level queue fill, [1 + l] shadow queue fill of lamp l
     uint32_t n_cnt32 = 0;
-    int closest_r = 2, anyhit_r = 2;          // rays per lane (tunable through HIPEXEC_CLOSEST_R / HIPEXEC_ANYHIT_R)
+    bool closest_lds = false, anyhit_lds = true;
+    int closest_r = 3, anyhit_r = 2;          // rays per lane (tunable through HIPEXEC_CLOSEST_R / HIPEXEC_ANYHIT_R)
     unsigned long long *d_cnt64 = nullptr;    // [0] any-hit triangle tests, [1] any-hit sphere tests
     uint32_t *h_cnt32 = nullptr;              // pinned
     unsigned long long *h_cnt64 = nullptr;    // pinned
@@ -333,7 +334,10 @@ int launch_anyhit_lamp_r(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t
 {
     uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
     const PairCam *pl = h->S.pair_lamp + (size_t)lamp * (h->S.n_tri_pad / 2);
-    LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit_lamp<MODE, R>), blocks_for(waves * 64), h->S, pl, rays, n, occl, lw, h->d_cnt64);
+    if (h->anyhit_lds)
+        LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit_lamp<MODE, R, true>), blocks_for(waves * 64), h->S, pl, rays, n, occl, lw, h->d_cnt64);
+    else
+        LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit_lamp<MODE, R, false>), blocks_for(waves * 64), h->S, pl, rays, n, occl, lw, h->d_cnt64);
     return HIPEXEC_OK;
 }
 template <int MODE>
@@ -350,7 +354,10 @@ template <int MODE, int R>
 int launch_closest_r(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 {
     uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
-    LAUNCH(HIPEXEC_K_CLOSEST, (k_closest<MODE, R>), blocks_for(waves * 64), h->S, rays, n, hits, h->d_cnt64);
+    if (h->closest_lds)
+        LAUNCH(HIPEXEC_K_CLOSEST, (k_closest<MODE, R, true>), blocks_for(waves * 64), h->S, rays, n, hits, h->d_cnt64);
+    else
+        LAUNCH(HIPEXEC_K_CLOSEST, (k_closest<MODE, R, false>), blocks_for(waves * 64), h->S, rays, n, hits, h->d_cnt64);
     return HIPEXEC_OK;
 }
 template <int MODE>
@@ -543,6 +550,8 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
         if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
+        if (const char *e = getenv("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
+        if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) h->anyhit_lds = atoi(e) != 0;
         HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 8 * sizeof(unsigned long long), h->stream));
         return build_scene(h, scene);
     }();

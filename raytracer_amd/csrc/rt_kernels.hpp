@@ -42,6 +42,12 @@ DEV void store_ray(float4 *rays, uint32_t j, f3 o, f3 d, uint32_t s, uint32_t au
 // ---------------------------------------------------------------------------------------
 // scene set-up: per-triangle records (runs once per hipexec_create)
 // ---------------------------------------------------------------------------------------
+// Triangle-pair records are staged through LDS in chunks of LDS_CHUNK pairs: the 4 waves of a
+// workgroup fetch each chunk from L2/HBM once (coalesced 16-byte loads, double buffered, next
+// chunk in flight during the tests of the current one) and read it back with uniform-address
+// ds_read_b128 broadcasts.
+constexpr int LDS_CHUNK = 64;
+
 constexpr float FILTER_KAPPA = 4e-6f;   // slack factor of the FILTER tests, ~5x the rounding bound
 constexpr float FILTER_NEVER = 1e30f;   // coefficient of a record that must never pass
 
@@ -356,14 +362,17 @@ __global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__re
 // ---------------------------------------------------------------------------------------
 // k_closest: closest hit of n queued rays, R rays per lane
 // ---------------------------------------------------------------------------------------
-template <int MODE, int R>
+template <int MODE, int R, bool LDS>
 __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restrict__ rays, uint32_t n,
                                                  float4 *__restrict__ hits, unsigned long long *__restrict__ counters)
 {
-    uint32_t n_groups = 0;
     constexpr int UP = 2;
-    uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    uint32_t lane = threadIdx.x & 63u;
+    constexpr int F4 = LDS_CHUNK * (int)(sizeof(PairGen) / 16);      // float4 per chunk (576)
+    __shared__ float4 lds[LDS ? 2 : 1][LDS ? F4 : 1];
+    uint32_t n_groups = 0;
+    const uint32_t tid = threadIdx.x;
+    uint32_t wave = (blockIdx.x * 256u + tid) >> 6;
+    uint32_t lane = tid & 63u;
     uint32_t base = wave * 64u * R + lane;
     f3 o[R], d[R]; RayF rf[R]; Best tb[R]; bool valid[R];
 #pragma unroll
@@ -377,36 +386,60 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
     }
     const PairGen *__restrict__ PG = S.pair_gen;
     const float4 *__restrict__ EX = S.tri_exact;
-    const uint32_t n_pairs = S.n_tri_pad / 2;
-    for (uint32_t jp = 0; jp < n_pairs; jp += UP) {
-        float acc[R];
+    const float4 *__restrict__ G = reinterpret_cast<const float4 *>(PG);
+    const uint32_t n_chunks = (S.n_tri_pad / 2) / LDS_CHUNK;
+    if (LDS) {
+        if (n_chunks) for (int k = 0; k < (F4 + 255) / 256; k++) if (tid + 256 * k < F4) lds[0][tid + 256 * k] = G[tid + 256 * k];
+        __syncthreads();
+    }
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        const int buf = LDS ? (int)(c & 1u) : 0;
+        float4 pre[(F4 + 255) / 256];
+        const bool more = c + 1 < n_chunks;
+        if (LDS && more) {
+            const float4 *g = G + (size_t)(c + 1) * F4;
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
-#pragma unroll
-        for (int k = 0; k < UP; k++) {
-            PairGen P = PG[jp + k];
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = filter_gen_pair(P, rf[r], acc[r]);
+            for (int k = 0; k < (F4 + 255) / 256; k++) if (tid + 256 * k < F4) pre[k] = g[tid + 256 * k];
         }
-        bool any = false;
+        const PairGen *L = LDS ? reinterpret_cast<const PairGen *>(&lds[buf][0]) : (PG + (size_t)c * LDS_CHUNK);
+        for (uint32_t jl = 0; jl < LDS_CHUNK; jl += UP) {
+            float acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) any |= !(acc[r] < rf[r].thr);
-        if (__ballot(any)) {
-            n_groups++;
+            for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < UP; k++) {
+                PairGen P = L[jl + k];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = filter_gen_pair(P, rf[r], acc[r]);
+            }
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) any |= !(acc[r] < rf[r].thr);
+            if (__ballot(any)) {
+                n_groups++;
 #pragma unroll 1
-            for (uint32_t ti = 2 * jp; ti < 2 * (jp + UP); ti++) {
-                PairGen P = PG[ti >> 1];
-                int h = (int)(ti & 1u);
-                float4 e0 = EX[3 * ti], e1 = EX[3 * ti + 1], e2 = EX[3 * ti + 2];
+                for (uint32_t tl = 2 * jl; tl < 2 * (jl + UP); tl++) {
+                    uint32_t ti = 2 * c * LDS_CHUNK + tl;
+                    PairGen P = L[tl >> 1];
+                    int h = (int)(tl & 1u);
+                    float4 e0 = EX[3 * ti], e1 = EX[3 * ti + 1], e2 = EX[3 * ti + 2];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    if (!(filter_gen_one(P, h, rf[r]) < rf[r].thr)) {
-                        float t, u, v;
-                        if (ti < S.n_tri && tri_exact<MODE>(o[r], d[r], xyz(e0), xyz(e1), xyz(e2), t, u, v))
-                            best_update<MODE>(tb[r], t, u, v, (int)ti);
+                    for (int r = 0; r < R; r++) {
+                        if (!(filter_gen_one(P, h, rf[r]) < rf[r].thr)) {
+                            float t, u, v;
+                            if (ti < S.n_tri && tri_exact<MODE>(o[r], d[r], xyz(e0), xyz(e1), xyz(e2), t, u, v))
+                                best_update<MODE>(tb[r], t, u, v, (int)ti);
+                        }
                     }
                 }
             }
+        }
+        if (LDS) {
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < (F4 + 255) / 256; k++) if (tid + 256 * k < F4) lds[buf ^ 1][tid + 256 * k] = pre[k];
+            }
+            __syncthreads();
         }
     }
     if (lane == 0 && n_groups) atomicAdd(&counters[3], (unsigned long long)n_groups);
@@ -509,20 +542,14 @@ __global__ __launch_bounds__(256) void k_anyhit(DScene S, const float4 *__restri
 // cheaper lamp-line FILTER (pair_lamp records of that lamp).  Exact tests and results are
 // those of k_anyhit.
 // ---------------------------------------------------------------------------------------
-// Triangle-pair records are staged through LDS in chunks of LDS_CHUNK pairs: the 4 waves of a
-// workgroup fetch each chunk from L2/HBM once (coalesced 16-byte loads, double buffered, next
-// chunk in flight during the tests of the current one) and read it back with uniform-address
-// ds_read_b128 broadcasts.
-constexpr int LDS_CHUNK = 64;
-
-template <int MODE, int R>
+template <int MODE, int R, bool LDS>
 __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__restrict__ PL, const float4 *__restrict__ rays,
                                                      uint32_t n, uint32_t *__restrict__ occl, uint32_t lw,
                                                      unsigned long long *__restrict__ counters)
 {
     constexpr int UP = 2;
     constexpr int F4 = LDS_CHUNK * (int)(sizeof(PairCam) / 16);      // float4 per chunk (320)
-    __shared__ float4 lds[2][F4];
+    __shared__ float4 lds[LDS ? 2 : 1][LDS ? F4 : 1];
     const uint32_t tid = threadIdx.x;
     uint32_t wave = (blockIdx.x * 256u + tid) >> 6;
     uint32_t lane = tid & 63u;
@@ -547,16 +574,18 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
     const float4 *__restrict__ EX = S.tri_exact;
     const float4 *__restrict__ G = reinterpret_cast<const float4 *>(PL);
     const uint32_t n_chunks = (S.n_tri_pad / 2) / LDS_CHUNK;
-    if (n_chunks) {
-        lds[0][tid] = G[tid];
-        if (tid < F4 - 256) lds[0][256 + tid] = G[256 + tid];
+    if (LDS) {
+        if (n_chunks) {
+            lds[0][tid] = G[tid];
+            if (tid < F4 - 256) lds[0][256 + tid] = G[256 + tid];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (uint32_t c = 0; c < n_chunks; c++) {
-        const int buf = (int)(c & 1u);
+        const int buf = LDS ? (int)(c & 1u) : 0;
         float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;
         const bool more = c + 1 < n_chunks;
-        if (more) {
+        if (LDS && more) {
             const float4 *g = G + (size_t)(c + 1) * F4;
             pre0 = g[tid];
             if (tid < F4 - 256) pre1 = g[256 + tid];
@@ -565,7 +594,7 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
 #pragma unroll
         for (int r = 0; r < R; r++) alive |= !done[r];
         if (__ballot(alive)) {
-            const PairCam *L = reinterpret_cast<const PairCam *>(&lds[buf][0]);
+            const PairCam *L = LDS ? reinterpret_cast<const PairCam *>(&lds[buf][0]) : (PL + (size_t)c * LDS_CHUNK);
             for (uint32_t jl = 0; jl < LDS_CHUNK; jl += UP) {
                 float acc[R];
 #pragma unroll
@@ -603,11 +632,13 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
         alive = false;
 #pragma unroll
         for (int r = 0; r < R; r++) alive |= !done[r];
-        if (more) {
-            lds[buf ^ 1][tid] = pre0;
-            if (tid < F4 - 256) lds[buf ^ 1][256 + tid] = pre1;
-        }
-        if (!__syncthreads_or(alive ? 1 : 0)) break;
+        if (LDS) {
+            if (more) {
+                lds[buf ^ 1][tid] = pre0;
+                if (tid < F4 - 256) lds[buf ^ 1][256 + tid] = pre1;
+            }
+            if (!__syncthreads_or(alive ? 1 : 0)) break;
+        } else if (__ballot(alive) == 0) break;
     }
     unsigned long long a = 0, b = 0;
 #pragma unroll
