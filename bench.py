@@ -35,6 +35,27 @@ WORKLOADS = {
 KNAMES = ["k_primary", "k_closest", "k_anyhit", "shade/resolve"]
 
 
+def measured_traffic(kernel_class, workload):
+    """HBM bytes per launch of a kernel class from the newest committed PMC summary
+    (profiles/rNN_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, collected
+    in separate rocprofv3 --pmc passes on the C2 workload).  None when no summary applies."""
+    import glob
+    if workload != "c2":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        summ = json.load(open(files[-1]))
+        for name, m in summ.items():
+            if name.startswith("rt::" + kernel_class) and m.get("launches_per_frame"):
+                if "hbm_read_bytes_corrected" in m and "hbm_write_bytes" in m:
+                    return (m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]) / m["launches_per_frame"]
+    except Exception:
+        return None
+    return None
+
+
 def class_flops(st, k, n_sph):
     if k == 0:
         return st.tests_tri_primary * F_TRI + st.rays_primary * n_sph * F_SPH
@@ -159,7 +180,8 @@ def main():
                        "partition": f"interleaved 8-row tiles over {world} GPU(s), gather to rank 0",
                        "rays_per_frame": rays_total / args.steps},
             "roofline": {"bound": "valu", "kernel": KNAMES[dom], "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": measured_traffic(KNAMES[dom], args.workload),
                          "flop_model": "44 FLOP per ray-triangle test + 25 per ray-sphere test, tests counted in the reference's scan order",
                          "avg_launch_ms": agg[f"ms{dom}"] / max(1, agg[f"l{dom}"]),
                          "kernel_ms_per_step": {KNAMES[k]: agg[f"ms{k}"] / args.steps for k in range(4)},

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarises gpurun_out/prof_<tag> (written by tools/profile_round.sh) into profiles/<tag>_*:
+kernel stats CSV, per-kernel PMC totals and derived metrics (VALU utilisation, HBM traffic with
+the gfx950 FETCH_SIZE correction, L2 hit rate)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
+    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(int)
+for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "rt::k_" not in k:
+            continue
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if "pmc_sq/" in f.replace("\\", "/") and r["Counter_Name"] == "SQ_WAVES":
+            disp[k] += 1
+# kernel durations from the trace (same command line, 2 timed steps + 1 warm-up = 3 frames)
+dur = collections.defaultdict(float); calls = collections.defaultdict(int)
+for f in glob.glob(f"{src}/trace/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "rt::k_" in k:
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; calls[k] += 1
+out = {}
+N_SIMD = 1024
+for k, c in tot.items():
+    d = dict(c)
+    # PMC runs render ONE frame; trace run renders 3
+    ms_frame = dur[k] / 3.0 if k in dur else None
+    gui = d.get("GRBM_GUI_ACTIVE", 0) / 8.0                 # summed over the 8 XCDs
+    m = {"counters": d, "ms_per_frame_from_trace": ms_frame, "launches_per_frame": calls[k] / 3.0 if k in calls else None}
+    if gui:
+        m["clock_ghz"] = gui / (ms_frame * 1e6) if ms_frame else None
+        # one wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts quad-cycles)
+        m["valu_utilisation"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
+        m["occupancy_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0) * 4.0 / (gui * N_SIMD)
+    if "FETCH_SIZE" in d:
+        # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reads half of a wide coalesced stream on gfx950 (x2 upper bound)
+        m["hbm_read_bytes_low"] = d["FETCH_SIZE"] * 1024.0
+        m["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 2048.0
+    if "WRITE_SIZE" in d:
+        m["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024.0
+    if d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0) > 0:
+        m["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+    out[k] = m
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+for k, m in sorted(out.items()):
+    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in m.items() if a != "counters"})
