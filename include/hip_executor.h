@@ -135,6 +135,8 @@ typedef struct hipexec_stats {
     uint64_t exact_groups[3];     /* per kernel class (primary, closest, any-hit): number of
                                      (wave, triangle group) pairs that left the filter-only path
                                      for exact tests; a diagnostic of filter selectivity        */
+    uint64_t scanned_chunks[3];   /* per kernel class: (wave, 128-triangle chunk) pairs actually scanned;
+                                     the rest were skipped by the bounding-box test                */
     uint32_t launches[HIPEXEC_K_COUNT];
     float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */
     float    total_ms;                     /* HIP-event time of the whole call on its stream */

@@ -44,7 +44,7 @@ class Stats(C.Structure):
         ("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("tests_tri_closest", C.c_uint64), ("tests_sph_closest", C.c_uint64),
         ("tests_tri_any", C.c_uint64), ("tests_sph_any", C.c_uint64),
-        ("tests_tri_primary", C.c_uint64), ("exact_groups", C.c_uint64 * 3),
+        ("tests_tri_primary", C.c_uint64), ("exact_groups", C.c_uint64 * 3), ("scanned_chunks", C.c_uint64 * 3),
         ("launches", C.c_uint32 * K_COUNT), ("kernel_ms", C.c_float * K_COUNT), ("total_ms", C.c_float),
     ]
 
@@ -53,6 +53,7 @@ class Stats(C.Structure):
             "rays_primary", "rays_bounce", "rays_shadow", "tests_tri_closest", "tests_sph_closest",
             "tests_tri_any", "tests_sph_any", "tests_tri_primary")}
         d["exact_groups"] = [int(x) for x in self.exact_groups]
+        d["scanned_chunks"] = [int(x) for x in self.scanned_chunks]
         d["launches"] = list(self.launches)
         d["kernel_ms"] = [float(x) for x in self.kernel_ms]
         d["total_ms"] = float(self.total_ms)

@@ -71,7 +71,7 @@ struct hipexec {
     Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
     uint32_t *d_cnt32 = nullptr;              // [0] next-level queue fill, [1 + l] shadow queue fill of lamp l
     uint32_t n_cnt32 = 0;
-    bool closest_lds = false, anyhit_lds = true;
+    bool closest_lds = false, anyhit_lds = false;
     int closest_r = 3, anyhit_r = 2;          // rays per lane (tunable through HIPEXEC_CLOSEST_R / HIPEXEC_ANYHIT_R)
     unsigned long long *d_cnt64 = nullptr;    // [0] any-hit triangle tests, [1] any-hit sphere tests
     uint32_t *h_cnt32 = nullptr;              // pinned
@@ -194,6 +194,18 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         }
     }
     S.pair_lamp = pl;
+    float4 *cb = nullptr;
+    uint32_t n_chunks = S.n_tri_pad / CHUNK_TRIS;
+    CHK(upload<float4>(h, nullptr, 0, &cb, 3 * (size_t)n_chunks + 1));
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_setup_chunks, dim3((n_chunks + 63) / 64), dim3(64), 0, h->stream, S.n_tri, n_chunks, d_p, d_e1, d_e2, cb);
+        HIPCHK(hipGetLastError());
+    }
+    S.chunk_box = cb;
+    {
+        const char *nc = getenv("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
+        S.cull = (nc && nc[0] == '1') ? 0u : 1u;
+    }
     float *d_norm = nullptr, *d_uv = nullptr; int *d_tmat = nullptr;
     CHK(upload(h, s->tri_norm, 3 * (size_t)s->n_tri, &d_norm));
     CHK(upload(h, s->tri_uv, s->tri_uv ? 6 * (size_t)s->n_tri : 0, &d_uv, 6 * (size_t)std::max(1u, s->n_tri)));
@@ -298,7 +310,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->acc.tests_tri_any = h->h_cnt64[0];
     h->acc.tests_sph_any = h->h_cnt64[1];
-    for (int k = 0; k < 3; k++) h->acc.exact_groups[k] = h->h_cnt64[2 + k];
+    for (int k = 0; k < 3; k++) { h->acc.exact_groups[k] = h->h_cnt64[2 + k]; h->acc.scanned_chunks[k] = h->h_cnt64[5 + k]; }
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {
         float ms = 0.f;

@@ -78,6 +78,10 @@ struct DScene {
     const PairCam *pair_cam;  // [n_tri_pad / 2]
     const PairGen *pair_gen;  // [n_tri_pad / 2]
     const PairCam *pair_lamp; // [n_lamp][n_tri_pad / 2], edge functions of lines through lamp l
+    // Bounding boxes of the index-contiguous chunks of CHUNK_TRIS triangles, 3 float4 per chunk:
+    // {centre, A} {half extent, e_abs} {A * |half extent|_1, 0, 0, 0} (see chunk_may_hit)
+    const float4 *chunk_box;
+    uint32_t cull;           // 1: skip chunks no ray of the wave can hit; 0: scan every chunk
     const float *tri_norm;   // [n][3]
     const float *tri_uv;     // [n][6]
     const int *tri_mat;      // [n]  (index n_mat = default material)

@@ -174,6 +174,86 @@ __global__ void k_setup_lamp_pairs(uint32_t n_tri, uint32_t n_pad, const float *
 }
 
 // ---------------------------------------------------------------------------------------
+// Chunk culling.  Triangles are scanned in chunks of CHUNK_TRIS consecutive indices; a chunk
+// whose (inflated) bounding box the half-line of a ray misses cannot contain a hit of that
+// ray, so a wave skips the chunk when that holds for all its rays.  Chunks are still visited
+// in index order, which keeps the lowest-index tie rule and the first-occluder order.
+//
+// The inflation makes the skip exact with respect to the EXACT tests, which accept hits
+// slightly outside a triangle: the barycentrics carry an absolute error of at most
+// 8*2^-24*|d||e||q| / |det| and the tests require |det| > 1e-4, so an accepted hit lies within
+// 9.6e-3*|d|*|e1||e2|*|q| of its triangle.  A = 2e-2 * max |e1||e2| over the chunk (2x margin),
+// |q| <= |o - centre|_1 + |half extent|_1, and e_abs covers the rounding of the slab test.
+// ---------------------------------------------------------------------------------------
+constexpr int CHUNK_TRIS = 2 * LDS_CHUNK;
+
+__global__ void k_setup_chunks(uint32_t n_tri, uint32_t n_chunks, const float *tp, const float *te1, const float *te2,
+                               float4 *chunk_box)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    float amax = 0.f; bool finite = true, any = false;
+    for (uint32_t i = c * CHUNK_TRIS; i < (c + 1) * CHUNK_TRIS && i < n_tri; i++) {
+        any = true;
+        float e1l = 0.f, e2l = 0.f;
+        for (int k = 0; k < 3; k++) {
+            float p = tp[3 * i + k], a = te1[3 * i + k], b = te2[3 * i + k];
+            float v1 = p + a, v2 = p + b;
+            lo[k] = fminf(lo[k], fminf(p, fminf(v1, v2))); hi[k] = fmaxf(hi[k], fmaxf(p, fmaxf(v1, v2)));
+            e1l += a * a; e2l += b * b;
+            finite = finite && (fabsf(p) < 3.0e38f) && (fabsf(v1) < 3.0e38f) && (fabsf(v2) < 3.0e38f);
+        }
+        amax = fmaxf(amax, sqrtf(e1l) * sqrtf(e2l));
+    }
+    float4 b0, b1, b2;
+    if (!any) {                       // padding only: nothing to hit
+        b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = make_float4(-1.f, -1.f, -1.f, 0.f); b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (!finite || !(amax < 1.0e30f)) {   // never skip
+        b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = make_float4(3.0e37f, 3.0e37f, 3.0e37f, 0.f); b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+        float hx = 0.5f * (hi[0] - lo[0]), hy = 0.5f * (hi[1] - lo[1]), hz = 0.5f * (hi[2] - lo[2]);
+        float mag = fabsf(cx) + fabsf(cy) + fabsf(cz) + hx + hy + hz;
+        float A = 2.0e-2f * amax;
+        float eabs = 1.0e-5f * mag + 1.0e-30f;
+        b0 = make_float4(cx, cy, cz, A);
+        b1 = make_float4(hx * 1.00001f, hy * 1.00001f, hz * 1.00001f, eabs);
+        b2 = make_float4(A * (hx + hy + hz) * 1.00001f, 0.f, 0.f, 0.f);
+    }
+    chunk_box[3 * c] = b0; chunk_box[3 * c + 1] = b1; chunk_box[3 * c + 2] = b2;
+}
+
+// per-ray constants of the slab test: origin, clamped reciprocal direction, |d|
+struct RayBox { f3 o, inv, ainv; float dlen; };
+DEV float safe_rcp(float x) {
+    float r = 1.0f / x;
+    if (!(fabsf(r) < 1.0e28f)) r = (__float_as_uint(x) >> 31) ? -1.0e28f : 1.0e28f;   // |x| tiny, zero or NaN
+    return r;
+}
+DEV RayBox raybox_make(f3 o, f3 d) {
+    RayBox r;
+    r.o = o;
+    r.inv = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    r.ainv = mk(fabsf(r.inv.x), fabsf(r.inv.y), fabsf(r.inv.z));
+    r.dlen = sqrtf(dot(d, d));
+    if (!(r.dlen < 3.0e38f)) r.dlen = 3.0e38f;
+    return r;
+}
+// true unless the half-line {o + t d, t >= 0} certainly misses the inflated box of the chunk
+DEV bool chunk_may_hit(const RayBox &r, float4 b0, float4 b1, float4 b2) {
+    float mx = b0.x - r.o.x, my = b0.y - r.o.y, mz = b0.z - r.o.z;
+    float m1 = (fabsf(mx) + fabsf(my)) + fabsf(mz);
+    float infl = fmaf(b0.w * r.dlen, m1, fmaf(b2.x, r.dlen, b1.w));
+    float hx = b1.x + infl, hy = b1.y + infl, hz = b1.z + infl;
+    float tcx = mx * r.inv.x, tcy = my * r.inv.y, tcz = mz * r.inv.z;
+    float thx = hx * r.ainv.x, thy = hy * r.ainv.y, thz = hz * r.ainv.z;
+    float tmin = fmaxf(fmaxf(tcx - thx, tcy - thy), tcz - thz);
+    float tmax = fminf(fminf(tcx + thx, tcy + thy), tcz + thz);
+    return !(tmax < fmaxf(tmin, 0.0f)) || !(infl < 3.0e37f);
+}
+
+// ---------------------------------------------------------------------------------------
 // FILTER tests (packed FP32: one instruction evaluates both triangles of a pair)
 // ---------------------------------------------------------------------------------------
 DEV v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -312,8 +392,22 @@ __global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__re
     const float thr = -S.theta;
     const PairCam *__restrict__ PC = S.pair_cam;
     const float4 *__restrict__ PX = S.tri_primx;
-    const uint32_t n_pairs = S.n_tri_pad / 2;
-    for (uint32_t jp = 0; jp < n_pairs; jp += UP) {
+    const float4 *__restrict__ CB = S.chunk_box;
+    const uint32_t n_chunks = (S.n_tri_pad / 2) / LDS_CHUNK;
+    RayBox rb[SPP];
+    uint32_t n_scanned = 0;
+#pragma unroll
+    for (int r = 0; r < SPP; r++) rb[r] = raybox_make(mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]), d[r]);
+    for (uint32_t c = 0; c < n_chunks; c++) {
+      if (S.cull) {
+        float4 b0 = CB[3 * c], b1 = CB[3 * c + 1], b2 = CB[3 * c + 2];
+        bool may = false;
+#pragma unroll
+        for (int r = 0; r < SPP; r++) may |= chunk_may_hit(rb[r], b0, b1, b2);
+        if (__ballot(may) == 0) continue;
+      }
+      n_scanned++;
+      for (uint32_t jp = c * LDS_CHUNK; jp < (c + 1) * LDS_CHUNK; jp += UP) {
         float acc[SPP];
 #pragma unroll
         for (int r = 0; r < SPP; r++) acc[r] = -3.0e38f;
@@ -343,8 +437,12 @@ __global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__re
                 }
             }
         }
+      }
     }
-    if ((threadIdx.x & 63u) == 0 && n_groups) atomicAdd(&counters[2], (unsigned long long)n_groups);
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_groups) atomicAdd(&counters[2], (unsigned long long)n_groups);
+        if (n_scanned) atomicAdd(&counters[5], (unsigned long long)n_scanned);
+    }
     f3 o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
 #pragma unroll
     for (int r = 0; r < SPP; r++) {
@@ -374,7 +472,8 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
     uint32_t wave = (blockIdx.x * 256u + tid) >> 6;
     uint32_t lane = tid & 63u;
     uint32_t base = wave * 64u * R + lane;
-    f3 o[R], d[R]; RayF rf[R]; Best tb[R]; bool valid[R];
+    f3 o[R], d[R]; RayF rf[R]; RayBox rb[R]; Best tb[R]; bool valid[R];
+    uint32_t n_scanned = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         uint32_t j = base + 64u * r;
@@ -382,10 +481,12 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
         uint32_t s, aux;
         load_ray(rays, valid[r] ? j : 0u, o[r], d[r], s, aux);
         rf[r] = rayf_make(S, o[r], d[r]);
+        rb[r] = raybox_make(o[r], d[r]);
         tb[r] = best_none();
     }
     const PairGen *__restrict__ PG = S.pair_gen;
     const float4 *__restrict__ EX = S.tri_exact;
+    const float4 *__restrict__ CB = S.chunk_box;
     const float4 *__restrict__ G = reinterpret_cast<const float4 *>(PG);
     const uint32_t n_chunks = (S.n_tri_pad / 2) / LDS_CHUNK;
     if (LDS) {
@@ -402,7 +503,16 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
             for (int k = 0; k < (F4 + 255) / 256; k++) if (tid + 256 * k < F4) pre[k] = g[tid + 256 * k];
         }
         const PairGen *L = LDS ? reinterpret_cast<const PairGen *>(&lds[buf][0]) : (PG + (size_t)c * LDS_CHUNK);
-        for (uint32_t jl = 0; jl < LDS_CHUNK; jl += UP) {
+        bool scan = true;
+        if (S.cull) {
+            float4 b0 = CB[3 * c], b1 = CB[3 * c + 1], b2 = CB[3 * c + 2];
+            bool may = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) may |= valid[r] && chunk_may_hit(rb[r], b0, b1, b2);
+            scan = __ballot(may) != 0;
+        }
+        if (scan) n_scanned++;
+        for (uint32_t jl = 0; scan && jl < LDS_CHUNK; jl += UP) {
             float acc[R];
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
@@ -442,7 +552,10 @@ __global__ __launch_bounds__(256) void k_closest(DScene S, const float4 *__restr
             __syncthreads();
         }
     }
-    if (lane == 0 && n_groups) atomicAdd(&counters[3], (unsigned long long)n_groups);
+    if (lane == 0) {
+        if (n_groups) atomicAdd(&counters[3], (unsigned long long)n_groups);
+        if (n_scanned) atomicAdd(&counters[6], (unsigned long long)n_scanned);
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         Best sb = spheres_closest<MODE>(S, o[r], d[r]);
@@ -479,12 +592,28 @@ __global__ __launch_bounds__(256) void k_anyhit(DScene S, const float4 *__restri
     }
     const PairGen *__restrict__ PG = S.pair_gen;
     const float4 *__restrict__ EX = S.tri_exact;
-    const uint32_t n_pairs = S.n_tri_pad / 2;
-    for (uint32_t jp = 0; jp < n_pairs; jp += UP) {
+    const float4 *__restrict__ CB = S.chunk_box;
+    const uint32_t n_chunks = (S.n_tri_pad / 2) / LDS_CHUNK;
+    RayBox rb[R];
+    uint32_t n_scanned = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) rb[r] = raybox_make(o[r], d[r]);
+    for (uint32_t c = 0; c < n_chunks; c++) {
+      {
         bool alive = false;
 #pragma unroll
         for (int r = 0; r < R; r++) alive |= !done[r];
         if (__ballot(alive) == 0) break;
+      }
+      if (S.cull) {
+        float4 b0 = CB[3 * c], b1 = CB[3 * c + 1], b2 = CB[3 * c + 2];
+        bool may = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) may |= !done[r] && chunk_may_hit(rb[r], b0, b1, b2);
+        if (__ballot(may) == 0) continue;
+      }
+      n_scanned++;
+      for (uint32_t jp = c * LDS_CHUNK; jp < (c + 1) * LDS_CHUNK; jp += UP) {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = -3.0e38f;
@@ -515,6 +644,7 @@ __global__ __launch_bounds__(256) void k_anyhit(DScene S, const float4 *__restri
                 }
             }
         }
+      }
     }
     unsigned long long a = 0, b = 0;
 #pragma unroll
@@ -534,6 +664,7 @@ __global__ __launch_bounds__(256) void k_anyhit(DScene S, const float4 *__restri
         if (a) atomicAdd(&counters[0], a);
         if (b) atomicAdd(&counters[1], b);
         if (n_groups) atomicAdd(&counters[4], (unsigned long long)n_groups);
+        if (n_scanned) atomicAdd(&counters[7], (unsigned long long)n_scanned);
     }
 }
 
@@ -555,9 +686,11 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
     uint32_t lane = tid & 63u;
     uint32_t base = wave * 64u * R + lane;
     uint32_t n_groups = 0;
-    f3 o[R], d[R], dn[R]; v2f Dx[R], Dy[R], Dz[R];
+    f3 o[R], d[R], dn[R]; v2f Dx[R], Dy[R], Dz[R]; RayBox rb[R];
     bool done[R], occluded[R]; uint32_t s[R], lamp[R], tri_tests[R], sph_tests[R];
     float thr[R];
+    uint32_t n_scanned = 0;
+    const float4 *__restrict__ CB = S.chunk_box;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         uint32_t j = base + 64u * r;
@@ -568,6 +701,7 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
         thr[r] = -S.theta;
         if (!(inv < 3.0e38f) || !(inv > 0.f) || !(thr[r] > -3.0e38f)) { dn[r] = mk(0.f, 0.f, 0.f); thr[r] = -3.0e38f; }
         Dx[r] = splat(dn[r].x); Dy[r] = splat(dn[r].y); Dz[r] = splat(dn[r].z);
+        rb[r] = raybox_make(o[r], d[r]);
         done[r] = !valid; occluded[r] = false;
         tri_tests[r] = valid ? S.n_tri : 0u; sph_tests[r] = valid ? S.n_sph : 0u;
     }
@@ -593,7 +727,16 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
         bool alive = false;
 #pragma unroll
         for (int r = 0; r < R; r++) alive |= !done[r];
-        if (__ballot(alive)) {
+        bool scan = __ballot(alive) != 0;
+        if (scan && S.cull) {
+            float4 b0 = CB[3 * c], b1 = CB[3 * c + 1], b2 = CB[3 * c + 2];
+            bool may = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) may |= !done[r] && chunk_may_hit(rb[r], b0, b1, b2);
+            scan = __ballot(may) != 0;
+        }
+        if (scan) {
+            n_scanned++;
             const PairCam *L = LDS ? reinterpret_cast<const PairCam *>(&lds[buf][0]) : (PL + (size_t)c * LDS_CHUNK);
             for (uint32_t jl = 0; jl < LDS_CHUNK; jl += UP) {
                 float acc[R];
@@ -658,6 +801,7 @@ __global__ __launch_bounds__(256) void k_anyhit_lamp(DScene S, const PairCam *__
         if (a) atomicAdd(&counters[0], a);
         if (b) atomicAdd(&counters[1], b);
         if (n_groups) atomicAdd(&counters[4], (unsigned long long)n_groups);
+        if (n_scanned) atomicAdd(&counters[7], (unsigned long long)n_scanned);
     }
 }
 

@@ -294,6 +294,30 @@ def scene_ties(seed=8) -> SceneSpec:
     return SceneSpec(V, F, UV, HAS, M, mats, sph, lamps, T, pos, None)
 
 
+def scene_soup(seed=9, n_tri=1500, extent=10.0) -> SceneSpec:
+    """Unordered triangle soup: sizes from 1e-3 to the whole scene, slivers, a few giant
+    triangles, shuffled so that consecutive indices share nothing spatially.  Stresses any
+    bound computed over index ranges."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform([-extent, 0.0, -2.0 * extent], [extent, 0.6 * extent, 0.0], size=(n_tri, 3))
+    size = 10.0 ** rng.uniform(-3.0, 0.3, size=(n_tri, 1, 1))
+    size[rng.integers(0, n_tri, 6)] = extent                              # giants
+    off = rng.normal(size=(n_tri, 3, 3)) * size
+    off[::7, 2] = off[::7, 1] * 1.01 + off[::7, 0] * 1e-2               # slivers
+    V = (c[:, None, :] + off).reshape(-1, 3).astype(np.float32)
+    F = np.arange(3 * n_tri, dtype=np.int64).reshape(n_tri, 3)
+    F = F[rng.permutation(n_tri)]
+    mats = [material(rng.uniform(0.2, 0.9, 3), kd=0.8, ks=0.4, hard=20, kr=0.3),
+            material(rng.uniform(0.2, 0.9, 3), kd=0.6, ks=0.8, hard=60, kr=0.0)]
+    fm = rng.integers(0, 2, n_tri).astype(np.int32)
+    sph = [{"center": [int(x) for x in rng.integers(-6, 6, 3) + np.array([0, 4, -10])], "radius": float(rng.uniform(0.5, 2.0)),
+            "material": int(i % 2)} for i in range(5)]
+    lamps = [{"pos": [3, 9, 2], "intensity": 1.0, "distance": 40.0}, {"pos": [-6, 5, -14], "intensity": 0.6, "distance": 30.0}]
+    T, pos = camera((0, 3, 9), pitch_deg=-6, yaw_deg=3)
+    return SceneSpec(V, F, None, None, fm, mats, sph, lamps, T, pos,
+                     {"ambientColor": [0.05, 0.05, 0.05], "horizonColor": [0.2, 0.3, 0.4], "ambientFactor": 0.0})
+
+
 def small_variant(name: str) -> SceneSpec:
     """Reduced-size versions of the benchmark scenes for parity tests."""
     return {
@@ -304,6 +328,7 @@ def small_variant(name: str) -> SceneSpec:
         "c5": lambda: scene_c5(cells=12, n_lamps=16, n_spheres=6),
         "mirror": scene_mirror_box,
         "ties": scene_ties,
+        "soup": scene_soup,
     }[name]()
 
 

@@ -1,0 +1,135 @@
+"""The chunk bounding-box test and the edge-function filter only ever skip work; neither may
+change a result.  These tests aim rays at the places where a conservative bound is most likely
+to be wrong (axis-parallel directions, origins on box faces and triangle planes, huge and tiny
+direction lengths, far-away origins, unordered geometry with loose boxes) and compare with the
+oracle bit for bit, and also compare the four on/off combinations of the two accelerations."""
+import os
+import numpy as np
+import pytest
+
+from raytracer_amd import _abi, scenegen
+
+pytestmark = pytest.mark.gpu
+CPU, CL = _abi.HIPEXEC_MODE_CPU, _abi.HIPEXEC_MODE_CL
+
+
+def _adversarial_rays(fs, seed, n_each=400):
+    rng = np.random.default_rng(seed)
+    p = np.asarray(fs.tri_p, np.float32).reshape(-1, 3)
+    e1 = np.asarray(fs.tri_e1, np.float32).reshape(-1, 3)
+    e2 = np.asarray(fs.tri_e2, np.float32).reshape(-1, 3)
+    nt = p.shape[0]
+    lo, hi = p.min(0) - 1.0, p.max(0) + 1.0
+    out = []
+    # 1. axis-parallel rays (two direction components exactly zero), origins on a lattice that
+    #    includes coordinates of triangle vertices (so rays run inside box faces)
+    for ax in range(3):
+        k = rng.integers(0, nt, n_each)
+        o = p[k] + (rng.integers(0, 2, (n_each, 1)) * e1[k]) + (rng.integers(0, 2, (n_each, 1)) * e2[k])
+        o[:, ax] = rng.choice([lo[ax], hi[ax]], n_each)
+        d = np.zeros((n_each, 3), np.float32)
+        d[:, ax] = np.where(o[:, ax] < 0.5 * (lo[ax] + hi[ax]), 1.0, -1.0) * rng.choice([1e-6, 1.0, 3e5], n_each)
+        out.append(np.concatenate([o, d], 1))
+    # 2. rays aimed exactly at vertices, edge midpoints and centroids from random origins
+    k = rng.integers(0, nt, 3 * n_each)
+    w = rng.choice([0.0, 0.5, 1.0 / 3.0, 1.0], (3 * n_each, 2)).astype(np.float32)
+    tgt = p[k] + w[:, :1] * e1[k] + w[:, 1:] * e2[k]
+    o = rng.uniform(lo, hi, (3 * n_each, 3)).astype(np.float32)
+    out.append(np.concatenate([o, (tgt - o) * rng.choice([1e-3, 1.0, 50.0], (3 * n_each, 1))], 1))
+    # 3. origins on a triangle's plane / inside the geometry, directions within the plane
+    k = rng.integers(0, nt, n_each)
+    o = p[k] + 0.3 * e1[k] + 0.3 * e2[k]
+    d = rng.normal(size=(n_each, 1)) * e1[k] + rng.normal(size=(n_each, 1)) * e2[k]
+    out.append(np.concatenate([o, d], 1))
+    # 4. far-away origins looking back at the scene, and rays pointing away from everything
+    c = 0.5 * (lo + hi)
+    dirs = rng.normal(size=(n_each, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    o = c + dirs * rng.choice([1e2, 1e4, 1e6], (n_each, 1))
+    tgt = rng.uniform(lo, hi, (n_each, 3))
+    sign = rng.choice([1.0, -1.0], (n_each, 1), p=[0.8, 0.2])
+    out.append(np.concatenate([o, sign * (tgt - o)], 1))
+    # 5. nearly axis-parallel: one dominant component, others denormal-small or 1e-30
+    o = rng.uniform(lo, hi, (n_each, 3))
+    d = rng.choice([1e-30, -1e-30, 1e-42, 0.0], (n_each, 3))
+    d[np.arange(n_each), rng.integers(0, 3, n_each)] = rng.choice([-1.0, 1.0], n_each)
+    out.append(np.concatenate([o, d], 1))
+    return np.ascontiguousarray(np.concatenate(out, 0), dtype=np.float32)
+
+
+@pytest.fixture(scope="module")
+def soup():
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    made = {}
+
+    def get(name):
+        if name not in made:
+            fs = scenegen.small_variant(name).to_flat()
+            made[name] = (fs, HipExecutor(fs, device=0), Oracle(fs))
+        return made[name]
+    yield get
+    for _, ex, _ in made.values():
+        ex.close()
+
+
+@pytest.mark.parametrize("mode", [CPU, CL])
+@pytest.mark.parametrize("name", ["soup", "c2", "c5"])
+def test_adversarial_rays_match_oracle(soup, name, mode):
+    fs, ex, orc = soup(name)
+    rays = _adversarial_rays(fs, 21)
+    ref = orc.closest_hits(rays, mode)
+    got = ex.closest_hits(rays, mode)
+    bad = np.nonzero(got["id"] != ref["id"])[0]
+    assert bad.size == 0, f"{bad.size} closest hits differ, first ray {bad[:5]}: {rays[bad[:5]]}"
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f].view(np.int32), ref[f].view(np.int32)), f
+    a_ref = orc.any_hits(rays, mode)
+    a_got = ex.any_hits(rays, mode)
+    bad = np.nonzero((a_got != 0) != (a_ref != 0))[0]
+    assert bad.size == 0, f"{bad.size} any-hit answers differ, first ray {bad[:5]}: {rays[bad[:5]]}"
+
+
+def test_soup_frame_matches_oracle(soup):
+    fs, ex, orc = soup("soup")
+    for mode, depth in ((CPU, 3), (CL, 0)):
+        ref = orc.render(64, 48, mode=mode, max_depth=depth, tone=0, n_threads=8)
+        got = ex.render(64, 48, mode=mode, max_depth=depth, tone=False)
+        assert np.array_equal(got["ids"], ref["ids"])
+        assert got["stats"].rays == ref["stats"].rays
+
+
+def test_accelerations_do_not_change_results(soup):
+    """Same scene, same rays: box culling on/off x edge filter on/off give identical bits."""
+    from raytracer_amd.executor import HipExecutor
+    results = []
+    saved = {k: os.environ.get(k) for k in ("HIPEXEC_NO_CULL", "HIPEXEC_NO_FILTER")}
+    try:
+        for name in ("soup", "c2"):
+            fs = scenegen.small_variant(name).to_flat()
+            rays = _adversarial_rays(fs, 5, n_each=150)
+            per = []
+            for no_cull in ("0", "1"):
+                for no_filter in ("0", "1"):
+                    os.environ["HIPEXEC_NO_CULL"] = no_cull
+                    os.environ["HIPEXEC_NO_FILTER"] = no_filter
+                    with HipExecutor(fs, device=0) as ex:
+                        h = ex.closest_hits(rays, CPU)
+                        a = ex.any_hits(rays, CPU)
+                        fr = ex.render(72, 40, mode=CPU, max_depth=2, tone=False)
+                        per.append((h["id"].copy(), h["t"].view(np.int32).copy(), a.copy(),
+                                    fr["ids"].copy(), fr["rgb"].view(np.int32).copy(),
+                                    list(fr["stats"].scanned_chunks)))
+            results.append(per)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for per in results:
+        base = per[0]
+        for other in per[1:]:
+            for x, y in zip(base[:5], other[:5]):
+                assert np.array_equal(x, y)
+        # culling really was active in the first configuration and off in the third
+        assert sum(per[0][5]) < sum(per[2][5])

@@ -14,4 +14,4 @@ out = np.zeros((H, W, 3), np.float32)
 for i in range(n):
     r = ex.render(W, H, max_depth=depth, want_ids=False, time_kernels=True, out=out)
     st = r["stats"]
-    print(i, "total_ms", round(st.total_ms, 1), [round(x, 1) for x in st.kernel_ms], list(st.launches), "rays", st.rays, "exact_groups", list(st.exact_groups), flush=True)
+    print(i, "total_ms", round(st.total_ms, 1), [round(x, 1) for x in st.kernel_ms], list(st.launches), "rays", st.rays, "exact_groups", list(st.exact_groups), "scanned_chunks", list(st.scanned_chunks), flush=True)
