@@ -103,10 +103,20 @@ typedef struct hipexec_render_cfg {
     int32_t tile_first;   /* first 8-row tile rendered by this call                          */
     int32_t tile_step;    /* stride between rendered tiles (1 = whole frame; G = one of G
                              interleaved shards)                                            */
-    int32_t flags;        /* bit 0: time every kernel with HIP events (fills *_ms in stats)  */
+    int32_t flags;        /* HIPEXEC_FLAG_* bits                                             */
 } hipexec_render_cfg;
 
-#define HIPEXEC_FLAG_TIME_KERNELS 1
+#define HIPEXEC_FLAG_TIME_KERNELS 1   /* time every kernel with HIP events (fills *_ms in stats) */
+#define HIPEXEC_FLAG_SCAN         2   /* this call: index-order scans like the reference's loops
+                                         (the only algorithm that reports tests_*_any)           */
+#define HIPEXEC_FLAG_BVH          4   /* this call: bounding volume hierarchy (the default unless
+                                         the environment says HIPEXEC_ALGO=scan)                 */
+
+/* Both algorithms evaluate the same exact ray/primitive arithmetic and return identical hits and
+ * colours; they differ in which tests they can prove unnecessary. */
+enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };
+
+#define HIPEXEC_ABI_VERSION 2
 
 /* Kernel classes reported in hipexec_stats. */
 enum {
@@ -121,7 +131,8 @@ enum {
  * Work counters of one call.  A "ray" is one closest-hit or any-hit query.  tests_* is the
  * algorithmic number of ray-primitive tests of the reference's linear scans: n_tri + n_sph
  * per closest-hit ray; (index of the first occluder in scan order) + 1, or n_tri + n_sph
- * when unoccluded, per shadow ray.
+ * when unoccluded, per shadow ray.  tests_tri_any / tests_sph_any are only counted by
+ * HIPEXEC_ALGO_SCAN (the hierarchy does not visit triangles in index order) and are 0 otherwise.
  */
 typedef struct hipexec_stats {
     uint64_t rays_primary;
@@ -137,6 +148,11 @@ typedef struct hipexec_stats {
                                      for exact tests; a diagnostic of filter selectivity        */
     uint64_t scanned_chunks[3];   /* per kernel class: (wave, 128-triangle chunk) pairs actually scanned;
                                      the rest were skipped by the bounding-box test                */
+    uint64_t bvh_nodes[3];        /* per ray class (camera, other closest-hit, shadow): hierarchy
+                                     nodes visited, summed over rays (HIPEXEC_ALGO_BVH)            */
+    uint64_t bvh_tests[3];        /* per ray class: exact ray-triangle tests evaluated, summed over
+                                     rays (HIPEXEC_ALGO_BVH)                                       */
+    uint32_t algorithm;           /* HIPEXEC_ALGO_* the call ran with                             */
     uint32_t launches[HIPEXEC_K_COUNT];
     float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */
     float    total_ms;                     /* HIP-event time of the whole call on its stream */
@@ -169,6 +185,15 @@ void hipexec_destroy(hipexec_t *h);
  * HIP work (e.g. an RCCL gather) without a device-wide synchronisation.
  */
 int hipexec_set_stream(hipexec_t *h, void *stream);
+
+/*
+ * Algorithm (HIPEXEC_ALGO_*) of later calls that do not choose one through
+ * hipexec_render_cfg.flags, including the batch entry points.  The reference has one
+ * algorithm, the linear scans of ray_tracer.cpp:205-229 / opencl_executor.cpp:110-316
+ * (HIPEXEC_ALGO_SCAN keeps their visiting order); HIPEXEC_ALGO_BVH is the default.  A scene
+ * for which no hierarchy could be built (non-finite coordinates) is always scanned.
+ */
+int hipexec_set_algorithm(hipexec_t *h, int algorithm);
 
 /*
  * Replaces renderSceneCl (ray_tracer_cl.cpp:9-56, HIPEXEC_MODE_CL) and renderScene

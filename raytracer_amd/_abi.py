@@ -10,8 +10,11 @@ HIPEXEC_MODE_CPU = 0
 HIPEXEC_MODE_CL = 1
 HIPEXEC_TILE_ROWS = 8
 HIPEXEC_FLAG_TIME_KERNELS = 1
+HIPEXEC_FLAG_SCAN = 2
+HIPEXEC_FLAG_BVH = 4
+HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -45,6 +48,7 @@ class Stats(C.Structure):
         ("tests_tri_closest", C.c_uint64), ("tests_sph_closest", C.c_uint64),
         ("tests_tri_any", C.c_uint64), ("tests_sph_any", C.c_uint64),
         ("tests_tri_primary", C.c_uint64), ("exact_groups", C.c_uint64 * 3), ("scanned_chunks", C.c_uint64 * 3),
+        ("bvh_nodes", C.c_uint64 * 3), ("bvh_tests", C.c_uint64 * 3), ("algorithm", C.c_uint32),
         ("launches", C.c_uint32 * K_COUNT), ("kernel_ms", C.c_float * K_COUNT), ("total_ms", C.c_float),
     ]
 
@@ -54,6 +58,8 @@ class Stats(C.Structure):
             "tests_tri_any", "tests_sph_any", "tests_tri_primary")}
         d["exact_groups"] = [int(x) for x in self.exact_groups]
         d["scanned_chunks"] = [int(x) for x in self.scanned_chunks]
+        d["bvh_nodes"] = [int(x) for x in self.bvh_nodes]
+        d["bvh_tests"] = [int(x) for x in self.bvh_tests]
         d["launches"] = list(self.launches)
         d["kernel_ms"] = [float(x) for x in self.kernel_ms]
         d["total_ms"] = float(self.total_ms)
@@ -87,6 +93,7 @@ PROTOTYPES = {
     "hipexec_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(SceneDesc), C.c_int]),
     "hipexec_destroy": (None, [C.c_void_p]),
     "hipexec_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hipexec_set_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
     "hipexec_render": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "hipexec_render_device": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "hipexec_sync": (C.c_int, [C.c_void_p]),

@@ -15,6 +15,8 @@
 
 #include "hip_executor.h"
 #include "rt_kernels.hpp"
+#include "rt_bvh.hpp"
+#include <hipcub/hipcub.hpp>
 
 using namespace rt;
 
@@ -59,6 +61,7 @@ struct TimedLaunch { hipEvent_t a, b; int klass; };
 
 constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte shadow rays per batch
 constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk of the batch entry points
+constexpr int N_CNT64 = 16;                                  // device counters, see call_end
 
 }  // namespace
 
@@ -66,6 +69,10 @@ struct hipexec {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     DScene S{};
+    DBvh B{};
+    bool bvh_ok = false;                      // a hierarchy exists for this scene
+    bool bvh_default = true;                  // algorithm of calls that do not choose (HIPEXEC_ALGO=scan|bvh)
+    bool use_bvh = false;                     // algorithm of the call in progress
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;
     Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
@@ -130,6 +137,69 @@ int validate_scene(const hipexec_scene_desc *s)
     return HIPEXEC_OK;
 }
 
+// Hierarchy over the triangles (rt_bvh.hpp).  Scenes with non-finite or astronomically large
+// coordinates, or too many triangles for the leaf encoding, get none and are always scanned.
+int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const double *hi, bool all_finite)
+{
+    const DScene &S = h->S;
+    DBvh &B = h->B;
+    const uint32_t n = S.n_tri;
+    B.n = n; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
+    B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
+    h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
+    float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
+    CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 1));
+    CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
+    CHK(upload<float4>(h, nullptr, 0, &nodes, 4 * (size_t)n + 1));
+    B.tris = tris; B.ids = ids; B.nodes = nodes;
+    if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
+    B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
+
+    // temporaries, released at the end
+    unsigned long long *keys_a = nullptr, *keys_b = nullptr;
+    uint32_t *child = nullptr, *parent = nullptr, *range = nullptr, *arrived = nullptr;
+    float4 *box_lo = nullptr, *box_hi = nullptr;
+    void *sort_tmp = nullptr;
+    std::vector<void *> tmp;
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        HIPCHK(hipMalloc(p, std::max<size_t>(bytes, 16)));
+        tmp.push_back(*p);
+        return HIPEXEC_OK;
+    };
+    int rc = [&]() -> int {
+        CHK(dalloc((void **)&keys_a, 8 * (size_t)n)); CHK(dalloc((void **)&keys_b, 8 * (size_t)n));
+        CHK(dalloc((void **)&child, 8 * (size_t)n)); CHK(dalloc((void **)&parent, 8 * (size_t)n));
+        CHK(dalloc((void **)&range, 8 * (size_t)n)); CHK(dalloc((void **)&arrived, 4 * (size_t)n));
+        CHK(dalloc((void **)&box_lo, 32 * (size_t)n)); CHK(dalloc((void **)&box_hi, 32 * (size_t)n));
+        HIPCHK(hipMemsetAsync(arrived, 0, 4 * (size_t)n, h->stream));
+        f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
+        float ext[3];
+        for (int k = 0; k < 3; k++) ext[k] = (float)(hi[k] - lo[k]);
+        inv.x = ext[0] > 0.f ? 1.0f / ext[0] : 0.f; inv.y = ext[1] > 0.f ? 1.0f / ext[1] : 0.f; inv.z = ext[2] > 0.f ? 1.0f / ext[2] : 0.f;
+        const dim3 blk(256), grid((n + 255) / 256);
+        hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
+        HIPCHK(hipGetLastError());
+        size_t tmp_bytes = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+        CHK(dalloc(&sort_tmp, tmp_bytes));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+        hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi);
+        HIPCHK(hipGetLastError());
+        if (n >= 2) {
+            hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_bvh_refit, grid, blk, 0, h->stream, n, child, parent, arrived, box_lo, box_hi);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, child, range, box_lo, box_hi, nodes);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return HIPEXEC_OK;
+    }();
+    for (void *p : tmp) (void)hipFree(p);
+    return rc;
+}
+
 int build_scene(hipexec *h, const hipexec_scene_desc *s)
 {
     DScene &S = h->S;
@@ -142,9 +212,13 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
 
     // centre of the scene's bounding box: origin of the FILTER coordinates
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool all_finite = true;
     auto grow = [&](double x, double y, double z) {
         double v[3] = {x, y, z};
-        for (int k = 0; k < 3; k++) if (std::isfinite(v[k])) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); }
+        for (int k = 0; k < 3; k++) {
+            if (std::isfinite(v[k]) && std::fabs(v[k]) < 1e18) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); }
+            else all_finite = false;
+        }
     };
     for (uint32_t i = 0; i < s->n_tri; i++) {
         const float *p = s->tri_p + 3 * (size_t)i, *a = s->tri_e1 + 3 * (size_t)i, *b = s->tri_e2 + 3 * (size_t)i;
@@ -206,6 +280,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         const char *nc = getenv("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
     }
+    CHK(build_bvh(h, ex, lo, hi, all_finite));
     float *d_norm = nullptr, *d_uv = nullptr; int *d_tmat = nullptr;
     CHK(upload(h, s->tri_norm, 3 * (size_t)s->n_tri, &d_norm));
     CHK(upload(h, s->tri_uv, s->tri_uv ? 6 * (size_t)s->n_tri : 0, &d_uv, 6 * (size_t)std::max(1u, s->n_tri)));
@@ -288,16 +363,18 @@ int timed_end(hipexec *h)
 
 inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
-int call_begin(hipexec *h, bool timing)
+int call_begin(hipexec *h, bool timing, uint32_t flags = 0)
 {
     HIPCHK(hipSetDevice(h->device));
+    bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
+    h->use_bvh = want_bvh && h->bvh_ok;
     if (h->call_open) {   // a previous asynchronous call has not been collected yet
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     h->timing = timing;
     memset(&h->acc, 0, sizeof h->acc);
     h->call_open = true;
-    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     return HIPEXEC_OK;
 }
@@ -306,11 +383,15 @@ int call_begin(hipexec *h, bool timing)
 int call_end(hipexec *h, hipexec_stats *stats)
 {
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, N_CNT64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->acc.tests_tri_any = h->h_cnt64[0];
     h->acc.tests_sph_any = h->h_cnt64[1];
-    for (int k = 0; k < 3; k++) { h->acc.exact_groups[k] = h->h_cnt64[2 + k]; h->acc.scanned_chunks[k] = h->h_cnt64[5 + k]; }
+    for (int k = 0; k < 3; k++) {
+        h->acc.exact_groups[k] = h->h_cnt64[2 + k]; h->acc.scanned_chunks[k] = h->h_cnt64[5 + k];
+        h->acc.bvh_nodes[k] = h->h_cnt64[8 + k]; h->acc.bvh_tests[k] = h->h_cnt64[11 + k];
+    }
+    h->acc.algorithm = h->use_bvh ? HIPEXEC_ALGO_BVH : HIPEXEC_ALGO_SCAN;
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {
         float ms = 0.f;
@@ -335,6 +416,10 @@ int read_count(hipexec *h, int which, uint32_t *out)
 template <int MODE>
 int launch_anyhit(hipexec *h, const float4 *rays, uint32_t n, uint32_t *occl, uint32_t lw)
 {
+    if (h->use_bvh) {
+        LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_anyhit<MODE>), blocks_for(n), h->S, h->B, rays, n, occl, lw, h->d_cnt64);
+        return HIPEXEC_OK;
+    }
     constexpr int R = 2;
     uint64_t waves = ((uint64_t)n + 64 * R - 1) / (64 * R);
     LAUNCH(HIPEXEC_K_ANYHIT, (k_anyhit<MODE, R>), blocks_for(waves * 64), h->S, rays, n, occl, lw, h->d_cnt64);
@@ -355,6 +440,7 @@ int launch_anyhit_lamp_r(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t
 template <int MODE>
 int launch_anyhit_lamp(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t n, uint32_t *occl, uint32_t lw)
 {
+    if (h->use_bvh) return launch_anyhit<MODE>(h, rays, n, occl, lw);
     switch (h->anyhit_r) {
     case 1: return launch_anyhit_lamp_r<MODE, 1>(h, lamp, rays, n, occl, lw);
     case 4: return launch_anyhit_lamp_r<MODE, 4>(h, lamp, rays, n, occl, lw);
@@ -375,6 +461,10 @@ int launch_closest_r(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 template <int MODE>
 int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 {
+    if (h->use_bvh) {
+        LAUNCH(HIPEXEC_K_CLOSEST, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, 1);
+        return HIPEXEC_OK;
+    }
     switch (h->closest_r) {
     case 1: return launch_closest_r<MODE, 1>(h, rays, n, hits);
     case 3: return launch_closest_r<MODE, 3>(h, rays, n, hits);
@@ -480,7 +570,13 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         uint64_t n0 = (uint64_t)F.n_slots * SPP;
         if (n0 > 0xfffffff0ull) return fail(HIPEXEC_E_LIMIT, "batch of %llu samples exceeds 32-bit indexing", (unsigned long long)n0);
         CHK(reserve_trace_buffers(h, n0, depth + 1));
-        LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>(), h->d_cnt64);
+        if (h->use_bvh) {
+            LAUNCH(HIPEXEC_K_PRIMARY, (k_raygen<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>());
+            LAUNCH(HIPEXEC_K_PRIMARY, (k_bvh_closest<MODE>), blocks_for(n0), S, h->B, h->rayA.as<float4>(), (uint32_t)n0,
+                   h->hit0.as<float4>(), h->d_cnt64, 0);
+        } else {
+            LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>(), h->d_cnt64);
+        }
         int rows = std::min(F.n_tiles * HIPEXEC_TILE_ROWS, c->height - F.tile_first * HIPEXEC_TILE_ROWS);
         if (c->tile_step != 1) {
             rows = 0;
@@ -532,7 +628,7 @@ int import_rays(hipexec *h, const float *rays6, uint32_t n)
 // =========================================================================================
 extern "C" {
 
-int hipexec_abi_version(void) { return 1; }
+int hipexec_abi_version(void) { return HIPEXEC_ABI_VERSION; }
 
 const char *hipexec_last_error(void) { return g_err; }
 
@@ -556,15 +652,16 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end));
         h->n_cnt32 = std::max(8u, scene->n_lamp + 1u);
         HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
-        HIPCHK(hipMalloc((void **)&h->d_cnt64, 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&h->d_cnt64, N_CNT64 * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&h->h_cnt64, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h->h_cnt64, N_CNT64 * sizeof(unsigned long long), hipHostMallocDefault));
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
         if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) h->anyhit_lds = atoi(e) != 0;
-        HIPCHK(hipMemsetAsync(h->d_cnt64, 0, 8 * sizeof(unsigned long long), h->stream));
+        if (const char *e = getenv("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
+        HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
         return build_scene(h, scene);
     }();
     if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
@@ -601,6 +698,14 @@ int hipexec_set_stream(hipexec_t *h, void *stream)
     return HIPEXEC_OK;
 }
 
+int hipexec_set_algorithm(hipexec_t *h, int algorithm)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (algorithm != HIPEXEC_ALGO_SCAN && algorithm != HIPEXEC_ALGO_BVH) return fail(HIPEXEC_E_INVALID, "unknown algorithm %d", algorithm);
+    h->bvh_default = algorithm == HIPEXEC_ALGO_BVH;
+    return HIPEXEC_OK;
+}
+
 int hipexec_sync(hipexec_t *h)
 {
     if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
@@ -620,7 +725,7 @@ int hipexec_render_device(hipexec_t *h, const hipexec_render_cfg *cfg, float *d_
     if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
     CHK(validate_cfg(cfg));
     if (!d_out_rgba) return fail(HIPEXEC_E_INVALID, "d_out_rgba is NULL");
-    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0));
+    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
     int rc = render_dispatch(h, cfg, reinterpret_cast<float4 *>(d_out_rgba), d_out_ids);
     if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
@@ -640,7 +745,7 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg, float *out_rgb, 
     HIPCHK(hipSetDevice(h->device));
     CHK(h->out_rgba.reserve(rows * W * 16));
     if (out_ids) CHK(h->out_ids.reserve(rows * W * 4 * spp));
-    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0));
+    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
     int rc = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
     if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
     CHK(call_end(h, stats));

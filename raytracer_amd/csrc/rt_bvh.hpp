@@ -1,0 +1,383 @@
+// rt_bvh.hpp — bounding volume hierarchy over the triangles: build kernels and the per-lane
+// traversal kernels (gfx950, wave64).
+//
+// The hierarchy only decides which EXACT tests are evaluated; every reported hit comes from
+// the same exact arithmetic as the linear scans, and the winner rule of the scans is kept
+// explicitly: smallest t, then smallest triangle index (ray_tracer.cpp:214,
+// opencl_executor.cpp:242).  Boxes are inflated per ray by more than the distance at which the
+// exact tests can still accept a hit outside its triangle (see TRay), so a subtree is skipped
+// only if no exact test in it can succeed.
+//
+// Build (all on the device, once per scene):
+//   k_bvh_keys    30-bit Morton code of each centroid, key = code << 32 | triangle index
+//   radix sort    hipcub::DeviceRadixSort on the 64-bit keys (unique by construction)
+//   k_bvh_leaves  triangle records gathered into key order, leaf boxes
+//   k_bvh_split   binary radix tree over the sorted keys, one thread per internal node
+//                 (longest-common-prefix construction; every node knows its key range)
+//   k_bvh_refit   boxes bottom-up, second thread to arrive at a node computes it
+//   k_bvh_emit    traversal nodes: both child boxes in one 64-byte record; subtrees with at
+//                 most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
+#pragma once
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
+constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
+constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_STACK = 32;                   // LDS stack entries per lane
+constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
+
+struct DBvh {
+    const float4 *nodes;    // 4 float4 per internal node: {lo0, A0} {hi0, ref0} {lo1, A1} {hi1, ref1}
+    const float4 *tris;     // 3 float4 per triangle in key order: {p, c21.x} {e1, c21.y} {e2, c21.z}
+    const uint32_t *ids;    // triangle index of the k-th record
+    uint32_t root;          // reference of the root (BVH_NONE for an empty scene)
+    uint32_t n;             // triangles
+    float scene_mag;        // bound on |coordinate| of any box corner
+};
+
+// ---------------------------------------------------------------------------------------
+// build
+// ---------------------------------------------------------------------------------------
+DEV uint32_t morton_spread(uint32_t v) {        // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext,
+                           unsigned long long *__restrict__ keys)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 p = xyz(tri_exact[3 * (size_t)i]), e1 = xyz(tri_exact[3 * (size_t)i + 1]), e2 = xyz(tri_exact[3 * (size_t)i + 2]);
+    f3 c = p + (e1 + e2) * (1.0f / 3.0f);
+    float q[3] = {(c.x - lo.x) * inv_ext.x, (c.y - lo.y) * inv_ext.y, (c.z - lo.z) * inv_ext.z};
+    uint32_t g[3];
+    for (int k = 0; k < 3; k++) {
+        float f = q[k] * 1024.0f;
+        g[k] = (f > 0.f) ? (f < 1023.0f ? (uint32_t)f : 1023u) : 0u;        // NaN -> 0
+    }
+    uint32_t code = morton_spread(g[0]) | (morton_spread(g[1]) << 1) | (morton_spread(g[2]) << 2);
+    keys[i] = ((unsigned long long)code << 32) | i;
+}
+
+// build-time node numbering: internal nodes 0 .. n-2, leaf k is node (n-1) + k
+__global__ void k_bvh_leaves(uint32_t n, const unsigned long long *__restrict__ keys, const float4 *__restrict__ tri_exact,
+                             float4 *__restrict__ tris, uint32_t *__restrict__ ids, float4 *__restrict__ box_lo,
+                             float4 *__restrict__ box_hi)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t i = (uint32_t)(keys[k] & 0xffffffffull);
+    float4 r0 = tri_exact[3 * (size_t)i], r1 = tri_exact[3 * (size_t)i + 1], r2 = tri_exact[3 * (size_t)i + 2];
+    tris[3 * (size_t)k] = r0; tris[3 * (size_t)k + 1] = r1; tris[3 * (size_t)k + 2] = r2;
+    ids[k] = i;
+    f3 p = xyz(r0), a = p + xyz(r1), b = p + xyz(r2);
+    f3 e1 = xyz(r1), e2 = xyz(r2);
+    float A = 2.0e-2f * (sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2)));
+    if (!(A < 3.0e38f)) A = 3.0e38f;
+    size_t node = (size_t)(n - 1) + k;
+    box_lo[node] = make_float4(fminf(p.x, fminf(a.x, b.x)), fminf(p.y, fminf(a.y, b.y)), fminf(p.z, fminf(a.z, b.z)), A);
+    box_hi[node] = make_float4(fmaxf(p.x, fmaxf(a.x, b.x)), fmaxf(p.y, fmaxf(a.y, b.y)), fmaxf(p.z, fmaxf(a.z, b.z)), 0.f);
+}
+
+// length of the common prefix of keys i and j, -1 outside [0, n)
+DEV int bvh_delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+__global__ void k_bvh_split(uint32_t n, const unsigned long long *__restrict__ keys, uint32_t *__restrict__ child,
+                            uint32_t *__restrict__ parent, uint32_t *__restrict__ range)
+{
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int N = (int)n;
+    if (i >= N - 1) return;
+    int d = (bvh_delta(keys, N, i, i + 1) - bvh_delta(keys, N, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = bvh_delta(keys, N, i, i - d);
+    int lmax = 2;
+    while (bvh_delta(keys, N, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (bvh_delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = bvh_delta(keys, N, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (bvh_delta(keys, N, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int first = min(i, j), last = max(i, j);
+    uint32_t left = (first == gamma) ? (uint32_t)(N - 1 + gamma) : (uint32_t)gamma;
+    uint32_t right = (last == gamma + 1) ? (uint32_t)(N - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    child[2 * i] = left; child[2 * i + 1] = right;
+    parent[left] = (uint32_t)i; parent[right] = (uint32_t)i;
+    range[2 * i] = (uint32_t)first; range[2 * i + 1] = (uint32_t)last;
+    if (i == 0) parent[0] = 0xffffffffu;
+}
+
+__global__ void k_bvh_refit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ parent,
+                            uint32_t *__restrict__ arrived, float4 *box_lo, float4 *box_hi)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || n < 2) return;
+    uint32_t cur = parent[(n - 1) + k];
+    while (cur != 0xffffffffu) {
+        __threadfence();
+        if (atomicAdd(&arrived[cur], 1u) == 0u) return;          // the sibling subtree is not finished yet
+        __threadfence();
+        uint32_t a = child[2 * cur], b = child[2 * cur + 1];
+        float4 la = box_lo[a], ha = box_hi[a], lb = box_lo[b], hb = box_hi[b];
+        box_lo[cur] = make_float4(fminf(la.x, lb.x), fminf(la.y, lb.y), fminf(la.z, lb.z), fmaxf(la.w, lb.w));
+        box_hi[cur] = make_float4(fmaxf(ha.x, hb.x), fmaxf(ha.y, hb.y), fmaxf(ha.z, hb.z), 0.f);
+        cur = parent[cur];
+    }
+}
+
+DEV uint32_t bvh_ref_of(uint32_t node, uint32_t n, const uint32_t *range) {
+    if (node >= n - 1) return BVH_LEAF | (1u << 28) | (node - (n - 1));
+    uint32_t first = range[2 * node], cnt = range[2 * node + 1] - first + 1;
+    if (cnt <= (uint32_t)BVH_LEAF_MAX) return BVH_LEAF | (cnt << 28) | first;
+    return node;
+}
+
+__global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ range,
+                           const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi, float4 *__restrict__ nodes)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 2 || i >= n - 1) return;
+    uint32_t a = child[2 * i], b = child[2 * i + 1];
+    float4 la = box_lo[a], ha = box_hi[a], lb = box_lo[b], hb = box_hi[b];
+    ha.w = __uint_as_float(bvh_ref_of(a, n, range));
+    hb.w = __uint_as_float(bvh_ref_of(b, n, range));
+    nodes[4 * (size_t)i] = la; nodes[4 * (size_t)i + 1] = ha; nodes[4 * (size_t)i + 2] = lb; nodes[4 * (size_t)i + 3] = hb;
+}
+
+// ---------------------------------------------------------------------------------------
+// traversal
+// ---------------------------------------------------------------------------------------
+// Per-ray constants.  A box with constant A is enlarged on every side by
+//     infl = A * dq + E,   dq = |d| * Q,   Q >= |o - p| for every triangle of the scene.
+// A = 2e-2 * max |e1||e2| over the subtree: the barycentrics and the ray parameter of the
+// exact tests carry an absolute error of at most 8*2^-24*|d||e1||e2||q| / |det| each and the
+// tests require |det| > 1e-4, so the point o + t*d of an accepted hit lies within
+// 9.6e-3*|d||e1||e2||q| (position units) of its triangle and A*dq is at least twice that.
+// E = 1e-6 * (|o|_1 + bound on box coordinates) covers the rounding of the slab arithmetic
+// itself (each face moves by less than 2^-22 of the magnitudes involved).
+struct TRay { f3 o, inv; float dq, E; };
+
+DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
+    TRay r;
+    r.o = o;
+    r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);        // +-inf for zero components: handled by the slab test
+    float dlen = sqrtf(dot(d, d));
+    float Q = ((fabsf(o.x - S.center[0]) + fabsf(o.y - S.center[1])) + fabsf(o.z - S.center[2])) + S.rmax;
+    r.dq = dlen * Q;
+    if (!(r.dq < 3.0e38f)) r.dq = 3.0e38f;
+    r.E = 1.0e-6f * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + B.scene_mag) + 1.0e-30f;
+    return r;
+}
+
+// entry parameter of the inflated box if the half-line t >= 0 may reach it at t <= limit
+DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float limit, float &tnear) {
+    float in = fmaf(lo.w, r.dq, r.E);
+    float t1x = ((lo.x - in) - r.o.x) * r.inv.x, t2x = ((hi.x + in) - r.o.x) * r.inv.x;
+    float t1y = ((lo.y - in) - r.o.y) * r.inv.y, t2y = ((hi.y + in) - r.o.y) * r.inv.y;
+    float t1z = ((lo.z - in) - r.o.z) * r.inv.z, t2z = ((hi.z + in) - r.o.z) * r.inv.z;
+    float tmin = max3f(fminf(t1x, t2x), fminf(t1y, t2y), fminf(t1z, t2z));
+    float tmax = min3f(fmaxf(t1x, t2x), fmaxf(t1y, t2y), fmaxf(t1z, t2z));
+    tnear = tmin;
+    return (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= limit);
+}
+
+// EXACT tests on a {p, e1, e2, c21} record: the bits of tri_exact_cpu / tri_exact_cl with
+// cross(e2, e1) read from the record (the same operations on the same inputs) and
+// cross(e1, e2) taken as its negation (exact up to the sign of zeros, which cannot change
+// an accepted hit: a zero dett is rejected by both t thresholds).
+template <int MODE>
+DEV bool tri_exact_rec(f3 o, f3 d, f3 p, f3 e1, f3 e2, f3 c21, float &t, float &u, float &v) {
+    f3 q = o - p;
+    float det = dot(d, c21);
+    if (MODE == HIPEXEC_MODE_CL) {
+        float dett = dot(q, -c21);
+        float detu = dot(d, cross(e2, q));
+        float detv = dot(d, cross(q, e1));
+        float tt = dett / det, uu = detu / det, vv = detv / det;
+        bool hit = (det > 0.001f || det < -0.001f);
+        hit = hit && (tt > 0.001f);
+        hit = hit && (uu > 0.0f && vv > 0.0f && uu + vv < 1.0f);
+        t = tt; u = uu; v = vv;
+        return hit;
+    }
+    if (fabsf(det) <= RT_EPSF) return false;
+    float dett = dot(q, -c21);
+    float tt = dett / det;
+    if (tt <= RT_EPSF) return false;
+    float detu = dot(d, cross(e2, q));
+    float detv = dot(d, cross(q, e1));
+    float uu = detu / det;
+    float vv = detv / det;
+    if (uu < 0.0f || vv < 0.0f || vv + uu > 1.0f) return false;
+    t = tt; u = uu; v = vv;
+    return true;
+}
+
+// winner rule of the linear scans made explicit: smaller t, then smaller triangle index
+DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
+    if (b.id < 0 || t < b.t || (t == b.t && id < b.id)) { b.t = t; b.u = u; b.v = v; b.id = id; }
+}
+
+// One ray per lane.  ANY = false: closest triangle hit into `best` (limit = largest t still of
+// interest, e.g. the sphere winner).  ANY = true: returns at the first accepted hit.
+// `stk` points at this lane's column of the LDS stack (entries 256 words apart).  A ray whose
+// stack would overflow is finished by a linear scan of all records, which gives the same
+// answer.
+template <int MODE, bool ANY>
+DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Best &best, uint32_t *stk,
+                      uint32_t &n_nodes, uint32_t &n_tris)
+{
+    uint32_t node = B.root;
+    int sp = 0;
+    bool overflow = false, found = false;
+    const float4 *__restrict__ T = B.tris;
+    while (node != BVH_NONE) {
+        if (!(node & BVH_LEAF)) {
+            const float4 *N = B.nodes + 4 * (size_t)node;
+            float4 l0 = N[0], h0 = N[1], l1 = N[2], h1 = N[3];
+            n_nodes++;
+            float t0, t1;
+            bool hit0 = bvh_box(r, l0, h0, limit, t0), hit1 = bvh_box(r, l1, h1, limit, t1);
+            uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
+            if (hit0 && hit1) {
+                bool swap = t1 < t0;
+                uint32_t far = swap ? r0 : r1;
+                node = swap ? r1 : r0;
+                if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
+                else { overflow = true; break; }
+            } else if (hit0) node = r0;
+            else if (hit1) node = r1;
+            else if (sp > 0) { sp--; node = stk[256 * sp]; }
+            else node = BVH_NONE;
+        } else {
+            uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
+            for (uint32_t k = first; k < first + cnt; k++) {
+                float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
+                n_tris++;
+                float t, u, v;
+                if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
+                    if (ANY) { found = true; break; }
+                    best_update_indexed(best, t, u, v, (int)B.ids[k]);
+                    limit = fminf(limit, best.t);
+                }
+            }
+            if (ANY && found) break;
+            if (sp > 0) { sp--; node = stk[256 * sp]; }
+            else node = BVH_NONE;
+        }
+    }
+    if (overflow) {
+        if (!ANY) best = best_none();
+        for (uint32_t k = 0; k < B.n && !(ANY && found); k++) {
+            float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
+            n_tris++;
+            float t, u, v;
+            if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
+                if (ANY) found = true;
+                else best_update_indexed(best, t, u, v, (int)B.ids[k]);
+            }
+        }
+    }
+    return found;
+}
+
+// camera rays of the pixel grid into ray records; sample s = r * n_slots + slot.  Slots
+// outside the frame get aux = 1 and a hit record with id -2, and are skipped by k_bvh_closest.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_raygen(DScene S, Frame F, float4 *__restrict__ rays, float4 *__restrict__ hits)
+{
+    constexpr int SPP = (MODE == HIPEXEC_MODE_CL) ? 1 : 4;
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    int x, y, lrow;
+    bool active = slot_to_pixel(F, slot, x, y, lrow);
+    if (slot >= F.n_slots) return;
+    if (!active) { x = min(x, F.W - 1); y = min(y, F.H - 1); }
+    f3 d[SPP];
+    camera_rays<MODE>(S, F, x, y, d);
+    f3 o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
+#pragma unroll
+    for (int r = 0; r < SPP; r++) {
+        uint32_t s = (uint32_t)r * F.n_slots + slot;
+        store_ray(rays, s, o, d[r], s, active ? 0u : 1u);
+        if (!active) hits[s] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
+    }
+}
+
+// counters[8 + klass] += nodes visited, counters[11 + klass] += exact triangle tests
+// (klass 0 camera rays, 1 other closest-hit rays, 2 shadow rays)
+DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris) {
+    unsigned long long a = wave_sum_u64(n_nodes), b = wave_sum_u64(n_tris);
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd(&counters[8 + klass], a);
+        if (b) atomicAdd(&counters[11 + klass], b);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+                                                     float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
+                                                     int klass)
+{
+    __shared__ uint32_t stack[BVH_STACK][256];
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    bool valid = j < n;
+    f3 o, d; uint32_t s, aux;
+    load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    valid = valid && aux == 0u;
+    uint32_t n_nodes = 0, n_tris = 0;
+    if (valid) {
+        Best sb = spheres_closest<MODE>(S, o, d);
+        Best tb = best_none();
+        TRay r = tray_make(S, B, o, d);
+        float limit = sb.id >= 0 ? sb.t : __builtin_inff();
+        bvh_traverse<MODE, false>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris);
+        hits[j] = merge_hits<MODE>(S, tb, sb);
+    }
+    bvh_count(counters, klass, n_nodes, n_tris);
+}
+
+// occlusion of queued shadow rays: bit `lamp` of occl[s * lw + lamp / 32] is set for occluded rays
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+                                                    uint32_t *__restrict__ occl, uint32_t lw,
+                                                    unsigned long long *__restrict__ counters)
+{
+    __shared__ uint32_t stack[BVH_STACK][256];
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    bool valid = j < n;
+    f3 o, d; uint32_t s, lamp;
+    load_ray(rays, valid ? j : 0u, o, d, s, lamp);
+    uint32_t n_nodes = 0, n_tris = 0;
+    if (valid) {
+        bool occluded = false;
+        for (uint32_t k = 0; k < S.n_sph && !occluded; k++) {
+            float4 sp = S.sph[k];
+            float t;
+            occluded = sph_exact<MODE>(o, d, xyz(sp), sp.w, t);
+        }
+        if (!occluded) {
+            TRay r = tray_make(S, B, o, d);
+            Best none = best_none();
+            occluded = bvh_traverse<MODE, true>(B, r, o, d, __builtin_inff(), none, &stack[0][threadIdx.x], n_nodes, n_tris);
+        }
+        if (occluded) atomicOr(&occl[(size_t)s * lw + (lamp >> 5)], 1u << (lamp & 31u));
+    }
+    bvh_count(counters, 2, n_nodes, n_tris);
+}
+
+}  // namespace rt

@@ -68,28 +68,36 @@ class HipExecutor:
 
     # -- frame ----------------------------------------------------------------------------
     @staticmethod
-    def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels):
+    def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo=None):
+        flags = _abi.HIPEXEC_FLAG_TIME_KERNELS if time_kernels else 0
+        if algo is not None:
+            flags |= {"scan": _abi.HIPEXEC_FLAG_SCAN, "bvh": _abi.HIPEXEC_FLAG_BVH}[algo]
         return _abi.RenderCfg(int(width), int(height), int(mode), int(max_depth), int(bool(tone)), int(tile_first),
-                              int(tile_step), _abi.HIPEXEC_FLAG_TIME_KERNELS if time_kernels else 0)
+                              int(tile_step), flags)
+
+    def set_algorithm(self, algo: str):
+        """Algorithm of calls that do not choose one: "bvh" (default) or "scan" (index-order scans)."""
+        self._check(self._lib.hipexec_set_algorithm(
+            self._h, {"scan": _abi.HIPEXEC_ALGO_SCAN, "bvh": _abi.HIPEXEC_ALGO_BVH}[algo]))
 
     def render(self, width, height, mode=HIPEXEC_MODE_CPU, max_depth=0, tone=True, tile_first=0, tile_step=1,
-               want_ids=True, time_kernels=False, out=None):
+               want_ids=True, time_kernels=False, out=None, algo=None):
         """Render to host memory.  -> dict(rgb [H][W][3] float32, ids [H][W][spp] int32 | None, stats)."""
         spp = 1 if mode == HIPEXEC_MODE_CL else 4
         rgb = out if out is not None else np.zeros((height, width, 3), np.float32)
         assert rgb.dtype == np.float32 and rgb.flags.c_contiguous and rgb.shape == (height, width, 3)
         ids = np.full((height, width, spp), -3, np.int32) if want_ids else None
         st = _abi.Stats()
-        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels)
+        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo)
         self._check(self._lib.hipexec_render(self._h, C.byref(cfg), rgb.ctypes.data,
                                              ids.ctypes.data if ids is not None else None, C.byref(st)))
         return {"rgb": rgb, "ids": ids, "stats": st}
 
     def render_device(self, width, height, d_out_rgba: int, d_out_ids: int | None = None, mode=HIPEXEC_MODE_CPU,
-                      max_depth=0, tone=True, tile_first=0, tile_step=1, time_kernels=False, stats=None):
+                      max_depth=0, tone=True, tile_first=0, tile_step=1, time_kernels=False, stats=None, algo=None):
         """Render into device memory (raw device pointers, e.g. torch.Tensor.data_ptr()).
         Asynchronous; call sync() before reading `stats`."""
-        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels)
+        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo)
         self._check(self._lib.hipexec_render_device(self._h, C.byref(cfg), C.c_void_p(d_out_rgba),
                                                     C.c_void_p(d_out_ids or 0),
                                                     C.byref(stats) if stats is not None else None))

@@ -1,5 +1,5 @@
-"""The chunk bounding-box test and the edge-function filter only ever skip work; neither may
-change a result.  These tests aim rays at the places where a conservative bound is most likely
+"""The hierarchy, the chunk bounding-box test and the edge-function filter only ever skip work;
+none of them may change a result.  These tests aim rays at the places where a conservative bound is most likely
 to be wrong (axis-parallel directions, origins on box faces and triangle planes, huge and tiny
 direction lengths, far-away origins, unordered geometry with loose boxes) and compare with the
 oracle bit for bit, and also compare the four on/off combinations of the two accelerations."""
@@ -72,10 +72,12 @@ def soup():
         ex.close()
 
 
+@pytest.mark.parametrize("algo", ["bvh", "scan"])
 @pytest.mark.parametrize("mode", [CPU, CL])
-@pytest.mark.parametrize("name", ["soup", "c2", "c5"])
-def test_adversarial_rays_match_oracle(soup, name, mode):
+@pytest.mark.parametrize("name", ["soup", "c2", "c5", "ties"])
+def test_adversarial_rays_match_oracle(soup, name, mode, algo):
     fs, ex, orc = soup(name)
+    ex.set_algorithm(algo)
     rays = _adversarial_rays(fs, 21)
     ref = orc.closest_hits(rays, mode)
     got = ex.closest_hits(rays, mode)
@@ -93,9 +95,10 @@ def test_soup_frame_matches_oracle(soup):
     fs, ex, orc = soup("soup")
     for mode, depth in ((CPU, 3), (CL, 0)):
         ref = orc.render(64, 48, mode=mode, max_depth=depth, tone=0, n_threads=8)
-        got = ex.render(64, 48, mode=mode, max_depth=depth, tone=False)
-        assert np.array_equal(got["ids"], ref["ids"])
-        assert got["stats"].rays == ref["stats"].rays
+        for algo in ("bvh", "scan"):
+            got = ex.render(64, 48, mode=mode, max_depth=depth, tone=False, algo=algo)
+            assert np.array_equal(got["ids"], ref["ids"]), algo
+            assert got["stats"].rays == ref["stats"].rays
 
 
 def test_accelerations_do_not_change_results(soup):
@@ -113,9 +116,10 @@ def test_accelerations_do_not_change_results(soup):
                     os.environ["HIPEXEC_NO_CULL"] = no_cull
                     os.environ["HIPEXEC_NO_FILTER"] = no_filter
                     with HipExecutor(fs, device=0) as ex:
+                        ex.set_algorithm("scan")
                         h = ex.closest_hits(rays, CPU)
                         a = ex.any_hits(rays, CPU)
-                        fr = ex.render(72, 40, mode=CPU, max_depth=2, tone=False)
+                        fr = ex.render(72, 40, mode=CPU, max_depth=2, tone=False, algo="scan")
                         per.append((h["id"].copy(), h["t"].view(np.int32).copy(), a.copy(),
                                     fr["ids"].copy(), fr["rgb"].view(np.int32).copy(),
                                     list(fr["stats"].scanned_chunks)))
@@ -126,7 +130,17 @@ def test_accelerations_do_not_change_results(soup):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    for per in results:
+    for (name, per) in zip(("soup", "c2"), results):
+        # the hierarchy gives the same bits as every scan configuration
+        fs = scenegen.small_variant(name).to_flat()
+        rays = _adversarial_rays(fs, 5, n_each=150)
+        with HipExecutor(fs, device=0) as ex:
+            h = ex.closest_hits(rays, CPU)
+            a = ex.any_hits(rays, CPU)
+            fr = ex.render(72, 40, mode=CPU, max_depth=2, tone=False, algo="bvh")
+            assert fr["stats"].algorithm == _abi.HIPEXEC_ALGO_BVH and sum(fr["stats"].bvh_nodes) > 0
+            per.append((h["id"].copy(), h["t"].view(np.int32).copy(), a.copy(), fr["ids"].copy(),
+                        fr["rgb"].view(np.int32).copy(), None))
         base = per[0]
         for other in per[1:]:
             for x, y in zip(base[:5], other[:5]):

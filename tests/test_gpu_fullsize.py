@@ -45,10 +45,12 @@ def test_c2_full_size_depth3():
         img = np.full((H, W, 3), -1, np.float32)
         rays = tri_any = 0
         for r in range(4):                                    # the 4-GPU partition, run on one GPU
-            p = ex.render(W, H, max_depth=depth, tile_first=r, tile_step=4, out=img, want_ids=False)
+            p = ex.render(W, H, max_depth=depth, tile_first=r, tile_step=4, out=img, want_ids=False, algo="scan")
             rays += p["stats"].rays; tri_any += p["stats"].tests_tri_any
         assert np.array_equal(img.view(np.int32), a["rgb"].view(np.int32)), "tile shards do not compose"
-        assert rays == a["stats"].rays and tri_any == a["stats"].tests_tri_any
+        s = ex.render(W, H, max_depth=depth, algo="scan")     # index-order scans: same frame bit for bit
+        assert np.array_equal(s["rgb"].view(np.int32), a["rgb"].view(np.int32)) and np.array_equal(s["ids"], a["ids"])
+        assert rays == a["stats"].rays == s["stats"].rays and tri_any == s["stats"].tests_tri_any > 0
     ids = a["ids"]
     assert ids.min() >= -1 and ids.max() < fs.n_tri + fs.n_sph
     assert (ids >= fs.n_tri).any() and (ids == -1).any() and ((ids >= 0) & (ids < fs.n_tri)).any()

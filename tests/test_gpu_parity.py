@@ -31,18 +31,23 @@ def backends():
 
 
 def _check_frame(ex, orc, W, H, mode, depth):
+    """Both algorithms of the executor against the oracle."""
     ref = orc.render(W, H, mode=mode, max_depth=depth, tone=1, n_threads=8)
-    got = ex.render(W, H, mode=mode, max_depth=depth, tone=True)
-    lin = ex.render(W, H, mode=mode, max_depth=depth, tone=False, want_ids=False)
-    assert np.array_equal(got["ids"], ref["ids"]), f"{(got['ids'] != ref['ids']).sum()} hit ids differ"
-    gs, rs = got["stats"], ref["stats"]
-    for k in ("rays_primary", "rays_bounce", "rays_shadow", "tests_tri_closest", "tests_sph_closest",
-              "tests_tri_any", "tests_sph_any", "tests_tri_primary"):
-        assert getattr(gs, k) == getattr(rs, k), k
-    u = ulp_diff(lin["rgb"], ref["linear"])
-    assert u.max() <= 4, f"linear colour off by {u.max()} ULP"
-    assert_image_parity(got["rgb"], ref["rgb"])
-    return float((u == 0).mean())
+    rs = ref["stats"]
+    for algo in ("bvh", "scan"):
+        got = ex.render(W, H, mode=mode, max_depth=depth, tone=True, algo=algo)
+        lin = ex.render(W, H, mode=mode, max_depth=depth, tone=False, want_ids=False, algo=algo)
+        assert np.array_equal(got["ids"], ref["ids"]), f"{algo}: {(got['ids'] != ref['ids']).sum()} hit ids differ"
+        gs = got["stats"]
+        assert gs.algorithm == {"scan": _abi.HIPEXEC_ALGO_SCAN, "bvh": _abi.HIPEXEC_ALGO_BVH}[algo]
+        keys = ["rays_primary", "rays_bounce", "rays_shadow", "tests_tri_closest", "tests_sph_closest", "tests_tri_primary"]
+        if algo == "scan":                       # only the index-order scans know the reference's any-hit test counts
+            keys += ["tests_tri_any", "tests_sph_any"]
+        for k in keys:
+            assert getattr(gs, k) == getattr(rs, k), (algo, k)
+        u = ulp_diff(lin["rgb"], ref["linear"])
+        assert u.max() <= 4, f"{algo}: linear colour off by {u.max()} ULP"
+        assert_image_parity(got["rgb"], ref["rgb"])
 
 
 @pytest.mark.parametrize("name", scenegen.SMALL_SCENES)
@@ -90,10 +95,12 @@ def _random_rays(fs, n, seed):
     return np.concatenate([o, d], axis=1).astype(np.float32)
 
 
+@pytest.mark.parametrize("algo", ["bvh", "scan"])
 @pytest.mark.parametrize("mode", [CPU, CL])
 @pytest.mark.parametrize("name", ["c2", "ties", "c5"])
-def test_batch_entry_points(backends, name, mode):
+def test_batch_entry_points(backends, name, mode, algo):
     fs, ex, orc = backends(name)
+    ex.set_algorithm(algo)
     rays = _random_rays(fs, 3000, 11)
     h_ref = orc.closest_hits(rays, mode)
     h_got = ex.closest_hits(rays, mode)
@@ -108,6 +115,7 @@ def test_batch_entry_points(backends, name, mode):
     base = np.full((rays.shape[0], 3), 0.25, np.float32)
     c_ref = orc.trace_rays(rays, mode, max_depth=2, colours=base.copy())
     c_got = ex.trace_rays(rays, mode, max_depth=2, colours=base.copy())
+    ex.set_algorithm("bvh")
     assert ulp_diff(c_got, c_ref).max() <= 4
 
 
