@@ -150,7 +150,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 1));
     CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
-    CHK(upload<float4>(h, nullptr, 0, &nodes, 4 * (size_t)n + 1));
+    CHK(upload<float4>(h, nullptr, 0, &nodes, 6 * (size_t)n + 1));
     B.tris = tris; B.ids = ids; B.nodes = nodes;
     if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
     B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
@@ -158,7 +158,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     // temporaries, released at the end
     unsigned long long *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *child = nullptr, *parent = nullptr, *range = nullptr, *arrived = nullptr;
-    float4 *box_lo = nullptr, *box_hi = nullptr;
+    float4 *box_lo = nullptr, *box_hi = nullptr, *nrm_lo = nullptr, *nrm_hi = nullptr;
     void *sort_tmp = nullptr;
     std::vector<void *> tmp;
     auto dalloc = [&](void **p, size_t bytes) -> int {
@@ -171,6 +171,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         CHK(dalloc((void **)&child, 8 * (size_t)n)); CHK(dalloc((void **)&parent, 8 * (size_t)n));
         CHK(dalloc((void **)&range, 8 * (size_t)n)); CHK(dalloc((void **)&arrived, 4 * (size_t)n));
         CHK(dalloc((void **)&box_lo, 32 * (size_t)n)); CHK(dalloc((void **)&box_hi, 32 * (size_t)n));
+        CHK(dalloc((void **)&nrm_lo, 32 * (size_t)n)); CHK(dalloc((void **)&nrm_hi, 32 * (size_t)n));
         HIPCHK(hipMemsetAsync(arrived, 0, 4 * (size_t)n, h->stream));
         f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
         float ext[3];
@@ -183,14 +184,14 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
         CHK(dalloc(&sort_tmp, tmp_bytes));
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
-        hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi);
+        hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi, nrm_lo, nrm_hi);
         HIPCHK(hipGetLastError());
         if (n >= 2) {
             hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(k_bvh_refit, grid, blk, 0, h->stream, n, child, parent, arrived, box_lo, box_hi);
+            hipLaunchKernelGGL(k_bvh_refit, grid, blk, 0, h->stream, n, child, parent, arrived, box_lo, box_hi, nrm_lo, nrm_hi);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, child, range, box_lo, box_hi, nodes);
+            hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, child, range, box_lo, box_hi, nrm_lo, nrm_hi, nodes);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(h->stream));

@@ -27,9 +27,12 @@ constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 4;
 constexpr int BVH_STACK = 32;                   // LDS stack entries per lane
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
+constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
+constexpr float BVH_TIGHT = 4.0e-6f;
+constexpr float BVH_TIGHT_MIN = 500.0f;         // tight bound used only if (|cos| * sine) >= BVH_TIGHT * BVH_TIGHT_MIN = 2e-3
 
 struct DBvh {
-    const float4 *nodes;    // 4 float4 per internal node: {lo0, A0} {hi0, ref0} {lo1, A1} {hi1, ref1}
+    const float4 *nodes;    // 6 float4 per internal node, 3 per child: {lo, A} {hi, ref} {cone axis * k, cone sine * k}
     const float4 *tris;     // 3 float4 per triangle in key order: {p, c21.x} {e1, c21.y} {e2, c21.z}
     const uint32_t *ids;    // triangle index of the k-th record
     uint32_t root;          // reference of the root (BVH_NONE for an empty scene)
@@ -69,7 +72,7 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
 // build-time node numbering: internal nodes 0 .. n-2, leaf k is node (n-1) + k
 __global__ void k_bvh_leaves(uint32_t n, const unsigned long long *__restrict__ keys, const float4 *__restrict__ tri_exact,
                              float4 *__restrict__ tris, uint32_t *__restrict__ ids, float4 *__restrict__ box_lo,
-                             float4 *__restrict__ box_hi)
+                             float4 *__restrict__ box_hi, float4 *__restrict__ nrm_lo, float4 *__restrict__ nrm_hi)
 {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -79,9 +82,22 @@ __global__ void k_bvh_leaves(uint32_t n, const unsigned long long *__restrict__ 
     ids[k] = i;
     f3 p = xyz(r0), a = p + xyz(r1), b = p + xyz(r2);
     f3 e1 = xyz(r1), e2 = xyz(r2);
-    float A = 2.0e-2f * (sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2)));
+    float ee = sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2));
+    float A = BVH_LOOSE * ee;
     if (!(A < 3.0e38f)) A = 3.0e38f;
     size_t node = (size_t)(n - 1) + k;
+    // unit normal (either sign: only |dot(d, n)| matters; one hemisphere is chosen so that the
+    // normals of a smooth patch stay together) and the sine of the angle between the edges
+    f3 c21 = mk(r0.w, r1.w, r2.w);
+    float cl = sqrtf(dot(c21, c21));
+    float sine = cl / ee;
+    f3 nn = c21 * (1.0f / cl);
+    if (!(cl > 0.f) || !(sine > 0.f) || !(sine < 2.f) || !(fabsf(nn.x) <= 1.f) || !(fabsf(nn.y) <= 1.f) || !(fabsf(nn.z) <= 1.f)) {
+        sine = 0.f; nn = mk(0.f, 0.f, 0.f);            // degenerate: never hit, and no tight bound for its ancestors
+    }
+    if (nn.x * 0.267f + nn.y * 0.535f + nn.z * 0.802f < 0.f) nn = -nn;
+    nrm_lo[node] = make_float4(nn.x, nn.y, nn.z, fminf(sine, 1.0f));
+    nrm_hi[node] = make_float4(nn.x, nn.y, nn.z, 0.f);
     box_lo[node] = make_float4(fminf(p.x, fminf(a.x, b.x)), fminf(p.y, fminf(a.y, b.y)), fminf(p.z, fminf(a.z, b.z)), A);
     box_hi[node] = make_float4(fmaxf(p.x, fmaxf(a.x, b.x)), fmaxf(p.y, fmaxf(a.y, b.y)), fmaxf(p.z, fmaxf(a.z, b.z)), 0.f);
 }
@@ -123,7 +139,8 @@ __global__ void k_bvh_split(uint32_t n, const unsigned long long *__restrict__ k
 }
 
 __global__ void k_bvh_refit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ parent,
-                            uint32_t *__restrict__ arrived, float4 *box_lo, float4 *box_hi)
+                            uint32_t *__restrict__ arrived, float4 *box_lo, float4 *box_hi, float4 *nrm_lo,
+                            float4 *nrm_hi)
 {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n || n < 2) return;
@@ -136,6 +153,9 @@ __global__ void k_bvh_refit(uint32_t n, const uint32_t *__restrict__ child, cons
         float4 la = box_lo[a], ha = box_hi[a], lb = box_lo[b], hb = box_hi[b];
         box_lo[cur] = make_float4(fminf(la.x, lb.x), fminf(la.y, lb.y), fminf(la.z, lb.z), fmaxf(la.w, lb.w));
         box_hi[cur] = make_float4(fmaxf(ha.x, hb.x), fmaxf(ha.y, hb.y), fmaxf(ha.z, hb.z), 0.f);
+        float4 na = nrm_lo[a], ma = nrm_hi[a], nb = nrm_lo[b], mb = nrm_hi[b];
+        nrm_lo[cur] = make_float4(fminf(na.x, nb.x), fminf(na.y, nb.y), fminf(na.z, nb.z), fminf(na.w, nb.w));
+        nrm_hi[cur] = make_float4(fmaxf(ma.x, mb.x), fmaxf(ma.y, mb.y), fmaxf(ma.z, mb.z), 0.f);
         cur = parent[cur];
     }
 }
@@ -147,8 +167,25 @@ DEV uint32_t bvh_ref_of(uint32_t node, uint32_t n, const uint32_t *range) {
     return node;
 }
 
+// Cone of the unit normals inside the box [nl, nh], scaled for bvh_box: returns {a * k, sin * k}
+// with k = cos_bound * sine_min / BVH_TIGHT, or a record that disables the tight bound.
+DEV float4 bvh_cone(float4 nl, float4 nh) {
+    f3 cen = mk(0.5f * (nl.x + nh.x), 0.5f * (nl.y + nh.y), 0.5f * (nl.z + nh.z));
+    f3 half = mk(0.5f * (nh.x - nl.x), 0.5f * (nh.y - nl.y), 0.5f * (nh.z - nl.z));
+    float len = sqrtf(dot(cen, cen));
+    float spread = sqrtf(dot(half, half)) * 1.0001f + 1.0e-6f;
+    // every unit normal u in the box has dot(u, cen/len) >= len - spread
+    float ca = fminf(len - spread, 1.0f), smin = nl.w;
+    if (!(ca > 1.0e-3f) || !(smin > 1.0e-6f)) return make_float4(0.f, 0.f, 0.f, 3.0e38f);
+    float sa = sqrtf(fmaxf(0.f, 1.0f - ca * ca)) * 1.0001f + 1.0e-7f;
+    float k = smin / BVH_TIGHT;
+    f3 a = cen * (1.0f / len);
+    return make_float4(a.x * (ca * k), a.y * (ca * k), a.z * (ca * k), sa * k);
+}
+
 __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ range,
-                           const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi, float4 *__restrict__ nodes)
+                           const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
+                           const float4 *__restrict__ nrm_lo, const float4 *__restrict__ nrm_hi, float4 *__restrict__ nodes)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < 2 || i >= n - 1) return;
@@ -156,40 +193,57 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
     float4 la = box_lo[a], ha = box_hi[a], lb = box_lo[b], hb = box_hi[b];
     ha.w = __uint_as_float(bvh_ref_of(a, n, range));
     hb.w = __uint_as_float(bvh_ref_of(b, n, range));
-    nodes[4 * (size_t)i] = la; nodes[4 * (size_t)i + 1] = ha; nodes[4 * (size_t)i + 2] = lb; nodes[4 * (size_t)i + 3] = hb;
+    float4 *N = nodes + 6 * (size_t)i;
+    N[0] = la; N[1] = ha; N[2] = bvh_cone(nrm_lo[a], nrm_hi[a]);
+    N[3] = lb; N[4] = hb; N[5] = bvh_cone(nrm_lo[b], nrm_hi[b]);
 }
 
 // ---------------------------------------------------------------------------------------
 // traversal
 // ---------------------------------------------------------------------------------------
-// Per-ray constants.  A box with constant A is enlarged on every side by
-//     infl = A * dq + E,   dq = |d| * Q,   Q >= |o - p| for every triangle of the scene.
-// A = 2e-2 * max |e1||e2| over the subtree: the barycentrics and the ray parameter of the
-// exact tests carry an absolute error of at most 8*2^-24*|d||e1||e2||q| / |det| each and the
-// tests require |det| > 1e-4, so the point o + t*d of an accepted hit lies within
-// 9.6e-3*|d||e1||e2||q| (position units) of its triangle and A*dq is at least twice that.
-// E = 1e-6 * (|o|_1 + bound on box coordinates) covers the rounding of the slab arithmetic
-// itself (each face moves by less than 2^-22 of the magnitudes involved).
-struct TRay { f3 o, inv; float dq, E; };
+// Per-ray constants of the box test.  A box is enlarged on every side by `infl`, chosen so that
+// the point o + t*d of every hit an EXACT test can accept for a triangle inside the box lies
+// inside the enlarged box.  With q = o - p, s = sine of the angle between e1 and e2 and
+// c = |cos| of the angle between d and the triangle normal, |det| = |d||e1||e2| s c, and the
+// rounding analysis of the tests gives (k <= 8 operations per determinant, eps = 2^-24):
+//   numerators  : |delta u||e1| + |delta v||e2| <= 2 * 8 eps |d||e1||e2||q| / |det|
+//   denominator : relative error of det <= 4 eps |d||e1||e2| s / |det|, moving the point by at
+//                 most (|e1| + |e2|) times that
+//   ray parameter t: the same two forms, times |d|
+// In a box whose corners are at most qb (L1) from o, |q| <= qb and |e1|, |e2| <= 2 qb, so
+//   error <= 1.92e-6 * qb / (s c)                         ("tight", scale free)
+//   error <= 1.92e-2 * |d| |e1||e2| * qb                  ("loose", from |det| > 1e-4)
+// Both are used with margin: A = BVH_LOOSE * max |e1||e2| over the subtree, and the tight form
+// with BVH_TIGHT when the normals of the subtree lie in a cone that keeps s*c >= 2e-3 for this
+// ray (g below is a lower bound of s*c / BVH_TIGHT).  E covers the rounding of the slab
+// arithmetic itself (each face moves by less than 2^-22 of the magnitudes involved).
+struct TRay { f3 o, inv, dhat; float dlen, E; };
 
 DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     TRay r;
     r.o = o;
     r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);        // +-inf for zero components: handled by the slab test
-    float dlen = sqrtf(dot(d, d));
-    float Q = ((fabsf(o.x - S.center[0]) + fabsf(o.y - S.center[1])) + fabsf(o.z - S.center[2])) + S.rmax;
-    r.dq = dlen * Q;
-    if (!(r.dq < 3.0e38f)) r.dq = 3.0e38f;
+    r.dlen = sqrtf(dot(d, d));
+    float il = 1.0f / r.dlen;
+    r.dhat = d * il;
+    if (!(r.dlen < 3.0e38f) || !(il < 3.0e38f)) { r.dlen = 3.0e38f; r.dhat = mk(0.f, 0.f, 0.f); }   // loose bound only
     r.E = 1.0e-6f * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + B.scene_mag) + 1.0e-30f;
     return r;
 }
 
-// entry parameter of the inflated box if the half-line t >= 0 may reach it at t <= limit
-DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float limit, float &tnear) {
-    float in = fmaf(lo.w, r.dq, r.E);
-    float t1x = ((lo.x - in) - r.o.x) * r.inv.x, t2x = ((hi.x + in) - r.o.x) * r.inv.x;
-    float t1y = ((lo.y - in) - r.o.y) * r.inv.y, t2y = ((hi.y + in) - r.o.y) * r.inv.y;
-    float t1z = ((lo.z - in) - r.o.z) * r.inv.z, t2z = ((hi.z + in) - r.o.z) * r.inv.z;
+// entry parameter of the enlarged box if the half-line t >= 0 may reach it at t <= limit
+DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float4 cone, float limit, float &tnear) {
+    float lx = lo.x - r.o.x, ly = lo.y - r.o.y, lz = lo.z - r.o.z;
+    float hx = hi.x - r.o.x, hy = hi.y - r.o.y, hz = hi.z - r.o.z;
+    float qb = (fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy))) + fmaxf(fabsf(lz), fabsf(hz));
+    float in = (lo.w * r.dlen) * qb;
+    float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
+    float tight = qb * __builtin_amdgcn_rcpf(g);
+    if (g >= BVH_TIGHT_MIN) in = fminf(in, tight);
+    in += r.E;
+    float t1x = (lx - in) * r.inv.x, t2x = (hx + in) * r.inv.x;
+    float t1y = (ly - in) * r.inv.y, t2y = (hy + in) * r.inv.y;
+    float t1z = (lz - in) * r.inv.z, t2z = (hz + in) * r.inv.z;
     float tmin = max3f(fminf(t1x, t2x), fminf(t1y, t2y), fminf(t1z, t2z));
     float tmax = min3f(fmaxf(t1x, t2x), fmaxf(t1y, t2y), fmaxf(t1z, t2z));
     tnear = tmin;
@@ -248,11 +302,11 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
     const float4 *__restrict__ T = B.tris;
     while (node != BVH_NONE) {
         if (!(node & BVH_LEAF)) {
-            const float4 *N = B.nodes + 4 * (size_t)node;
-            float4 l0 = N[0], h0 = N[1], l1 = N[2], h1 = N[3];
+            const float4 *N = B.nodes + 6 * (size_t)node;
+            float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
             n_nodes++;
             float t0, t1;
-            bool hit0 = bvh_box(r, l0, h0, limit, t0), hit1 = bvh_box(r, l1, h1, limit, t1);
+            bool hit0 = bvh_box(r, l0, h0, c0, limit, t0), hit1 = bvh_box(r, l1, h1, c1, limit, t1);
             uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
             if (hit0 && hit1) {
                 bool swap = t1 < t0;
