@@ -61,6 +61,7 @@ struct TimedLaunch { hipEvent_t a, b; int klass; };
 
 constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte shadow rays per batch
 constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk of the batch entry points
+constexpr uint64_t BATCH_MAX_SAMPLES = 64ull << 20;          // samples per batch of a frame without a shadow queue
 constexpr int N_CNT64 = 16;                                  // device counters, see call_end
 
 }  // namespace
@@ -392,6 +393,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
         h->acc.exact_groups[k] = h->h_cnt64[2 + k]; h->acc.scanned_chunks[k] = h->h_cnt64[5 + k];
         h->acc.bvh_nodes[k] = h->h_cnt64[8 + k]; h->acc.bvh_tests[k] = h->h_cnt64[11 + k];
     }
+    h->acc.rays_shadow += h->h_cnt64[14];
     h->acc.algorithm = h->use_bvh ? HIPEXEC_ALGO_BVH : HIPEXEC_ALGO_SCAN;
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {
@@ -487,7 +489,10 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
     int level = 0;
     for (;; level++) {
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
-        if (S.n_lamp) {
+        if (S.n_lamp && h->use_bvh) {
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), blocks_for(n), S, h->B, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
+                   h->lamp_words, h->d_cnt64);
+        } else if (S.n_lamp) {
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
                    h->shadowq.as<float4>(), h->d_cnt32 + 1);
             HIPCHK(hipMemcpyAsync(h->h_cnt32 + 1, h->d_cnt32 + 1, S.n_lamp * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -528,7 +533,7 @@ int reserve_trace_buffers(hipexec *h, uint64_t n0, int levels)
         CHK(h->occl.reserve(occl_bytes));
         HIPCHK(hipMemsetAsync(h->occl.p, 0, h->occl.cap, h->stream));
     }
-    CHK(h->shadowq.reserve(std::max<uint64_t>(1, n0 * h->S.n_lamp) * 32));
+    if (!h->use_bvh) CHK(h->shadowq.reserve(std::max<uint64_t>(1, n0 * h->S.n_lamp) * 32));
     return HIPEXEC_OK;
 }
 
@@ -562,6 +567,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
     uint64_t samples_per_tile = (uint64_t)nbx * 64 * SPP;
     uint64_t per_tile_entries = samples_per_tile * std::max(1u, S.n_lamp);
     int tiles_per_batch = (int)std::max<uint64_t>(1, SHADOW_QUEUE_MAX_ENTRIES / per_tile_entries);
+    if (h->use_bvh) tiles_per_batch = (int)std::max<uint64_t>(1, BATCH_MAX_SAMPLES / samples_per_tile);   // no shadow queue
     for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_batch) {
         Frame F;
         F.W = c->width; F.H = c->height; F.tile_step = c->tile_step;

@@ -434,4 +434,106 @@ __global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const floa
     bvh_count(counters, 2, n_nodes, n_tris);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_bvh_shadow: shadow rays of one level without a global queue.  A block owns 256 rays of the
+// level.  Per group of SH_LAMPS lamps it evaluates the facing tests (ray_tracer.cpp:174-182 /
+// ray_tracer_cl.cpp:138-143), compacts the (sample, lamp) pairs that cast a shadow ray into an
+// LDS list in lamp-major order (ballot + popcount, no global atomics), and then traces the
+// list 256 entries at a time, so waves stay full and their rays point at the same lamp from
+// neighbouring surface points.  Occluded pairs set bit `lamp` of occl[s * lw + lamp / 32].
+// counters[14] += shadow rays traced.
+// ---------------------------------------------------------------------------------------
+constexpr int SH_LAMPS = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const float4 *__restrict__ rays,
+                                                    const float4 *__restrict__ hits, uint32_t n,
+                                                    uint32_t *__restrict__ occl, uint32_t lw,
+                                                    unsigned long long *__restrict__ counters)
+{
+    __shared__ uint32_t stack[BVH_STACK][256];
+    __shared__ float Px[256], Py[256], Pz[256];
+    __shared__ uint32_t sample_of[256];
+    __shared__ uint16_t list[SH_LAMPS * 256];
+    __shared__ uint32_t wcnt[SH_LAMPS * 4 + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t j = blockIdx.x * 256u + tid;
+    bool valid = j < n;
+    f3 o, d; uint32_t s, aux;
+    load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    float4 h = hits[valid ? j : 0u];
+    bool hit = valid && __float_as_int(h.w) >= 0;
+    Surf sf;
+    if (hit) sf = surface(S, o, d, h, false);
+    else { sf.P = mk(0.f, 0.f, 0.f); sf.N = mk(0.f, 0.f, 1.f); }
+    Px[tid] = sf.P.x; Py[tid] = sf.P.y; Pz[tid] = sf.P.z;
+    sample_of[tid] = s;
+    const float dotWithDir = dot(d, sf.N);
+    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
+    for (uint32_t l0 = 0; l0 < S.n_lamp; l0 += SH_LAMPS) {
+        unsigned long long votes[SH_LAMPS];
+#pragma unroll
+        for (int li = 0; li < SH_LAMPS; li++) {
+            bool cast = false;
+            if (l0 + li < S.n_lamp) {
+                float4 lp = S.lamp[l0 + li];
+                f3 toLamp = xyz(lp) - sf.P;
+                cast = hit && casts_shadow_ray<MODE>(dotWithDir, dot(toLamp, sf.N));
+            }
+            votes[li] = __ballot(cast);
+            if (lane == 0) wcnt[li * 4 + w] = (uint32_t)__popcll(votes[li]);
+        }
+        __syncthreads();
+        if (tid < 64) {                     // exclusive prefix over (lamp, wave) in lamp-major order
+            uint32_t own = tid < SH_LAMPS * 4 ? wcnt[tid] : 0u, inc = own;
+            for (int off = 1; off < SH_LAMPS * 4; off <<= 1) {
+                uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+                if ((int)lane >= off) inc += up;
+            }
+            uint32_t total = (uint32_t)__shfl((int)inc, SH_LAMPS * 4 - 1);
+            if (tid < SH_LAMPS * 4) wcnt[tid] = inc - own;
+            if (tid == 0) wcnt[SH_LAMPS * 4] = total;
+        }
+        __syncthreads();
+        const uint32_t total = wcnt[SH_LAMPS * 4];
+#pragma unroll
+        for (int li = 0; li < SH_LAMPS; li++) {
+            if ((votes[li] >> lane) & 1ull) {
+                uint32_t pos = wcnt[li * 4 + w] + (uint32_t)__popcll(votes[li] & ((1ull << lane) - 1ull));
+                list[pos] = (uint16_t)(tid | ((uint32_t)li << 8));
+            }
+        }
+        __syncthreads();
+        uint32_t my_bits = 0;               // not used: results go out through atomics on the owner's word
+        (void)my_bits;
+        for (uint32_t base = 0; base < total; base += 256u) {
+            uint32_t e = base + tid;
+            if (e < total) {
+                uint32_t entry = list[e];
+                uint32_t t2 = entry & 255u, l = l0 + (entry >> 8);
+                f3 P = mk(Px[t2], Py[t2], Pz[t2]);
+                float4 lp = S.lamp[l];
+                f3 toLamp = xyz(lp) - P;
+                bool occluded = false;
+                for (uint32_t k = 0; k < S.n_sph && !occluded; k++) {
+                    float4 sp = S.sph[k];
+                    float t;
+                    occluded = sph_exact<MODE>(P, toLamp, xyz(sp), sp.w, t);
+                }
+                if (!occluded) {
+                    TRay r = tray_make(S, B, P, toLamp);
+                    Best none = best_none();
+                    occluded = bvh_traverse<MODE, true>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris);
+                }
+                if (occluded) atomicOr(&occl[(size_t)sample_of[t2] * lw + (l >> 5)], 1u << (l & 31u));
+                n_rays++;
+            }
+        }
+        __syncthreads();
+    }
+    bvh_count(counters, 2, n_nodes, n_tris);
+    unsigned long long nr = wave_sum_u64(n_rays);
+    if (lane == 0 && nr) atomicAdd(&counters[14], nr);
+}
+
 }  // namespace rt
