@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test
+F_NODE = 84.0                        # FLOP per visited hierarchy node (two enlarged-box slab tests, see bvh_box)
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA)
 
 WORKLOADS = {
@@ -32,17 +33,19 @@ WORKLOADS = {
     "tiny": ("scene_c2", {"cells": 24, "tex_size": 64}, 256, 144, 3, "tiny: 1152-tri C2 variant at 256x144 (functional check only)"),
 }
 
-KNAMES = ["k_primary", "k_closest", "k_anyhit", "shade/resolve"]
+KNAMES = {"scan": ["k_primary", "k_closest", "k_anyhit_lamp", "shade/resolve"],
+          "bvh": ["k_bvh_closest", "k_bvh_closest", "k_bvh_shadow", "shade/resolve"]}
+KLABEL = ["camera rays", "bounce rays", "shadow rays", "shading"]
 
 
-def measured_traffic(kernel_class, workload):
+def measured_traffic(kernel_class, workload, algo="bvh"):
     """HBM bytes per launch of a kernel class from the newest committed PMC summary
-    (profiles/rNN_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, collected
+    (profiles/rNN_<algo>_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, collected
     in separate rocprofv3 --pmc passes on the C2 workload).  None when no summary applies."""
     import glob
     if workload != "c2":
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{algo}_pmc_summary.json")))
     if not files:
         return None
     try:
@@ -57,6 +60,8 @@ def measured_traffic(kernel_class, workload):
 
 
 def class_flops(st, k, n_sph):
+    """Algorithmic FLOP of a ray class: the tests of the reference's linear scans (every
+    triangle and sphere per closest-hit ray; up to the first occluder per shadow ray)."""
     if k == 0:
         return st.tests_tri_primary * F_TRI + st.rays_primary * n_sph * F_SPH
     if k == 1:
@@ -64,6 +69,14 @@ def class_flops(st, k, n_sph):
     if k == 2:
         return st.tests_tri_any * F_TRI + st.tests_sph_any * F_SPH
     return 0.0
+
+
+def executed_flops(st, k, n_sph):
+    """FLOP the hierarchy kernels actually evaluated for a ray class (node visits + exact tests)."""
+    rays = [st.rays_primary, st.rays_bounce, st.rays_shadow][k] if k < 3 else 0
+    if k >= 3:
+        return 0.0
+    return st.bvh_nodes[k] * F_NODE + st.bvh_tests[k] * F_TRI + rays * n_sph * F_SPH
 
 
 def cpu_baseline(fs, W, H, depth, budget_s=20.0):
@@ -97,6 +110,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--algo", default="bvh", choices=["bvh", "scan", "brute"],
+                    help="bvh: hierarchy traversal (default); scan: index-order scans with chunk culling; "
+                         "brute: index-order scans of every triangle, the reference's own work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -122,6 +138,9 @@ def main():
 
     builder, kw, W, H, depth, desc = WORKLOADS[args.workload]
     fs = getattr(scenegen, builder)(**kw).to_flat()
+    if args.algo == "brute":
+        os.environ["HIPEXEC_NO_CULL"] = "1"
+    algo = "bvh" if args.algo == "bvh" else "scan"
     ex = HipExecutor(fs, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
     ex.set_stream(stream.cuda_stream)
@@ -134,7 +153,7 @@ def main():
         nonlocal frame
         with torch.cuda.stream(stream):
             ex.render_device(W, H, out.data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
-                             time_kernels=time_kernels, stats=st)
+                             time_kernels=time_kernels, stats=st, algo=algo)
             frame = gather_frame(out, H)
             ex.sync()
 
@@ -144,9 +163,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The algorithmic test counts of the reference's scans are a property of the frame; only the
+    # index-order scans can count the shadow-ray part, so take them from one untimed scan frame.
+    ref_flops = None
+    if algo == "bvh" and rank == 0:
+        st_scan = _abi.Stats()
+        with torch.cuda.stream(stream):
+            ex.render_device(W, H, out.data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
+                             stats=st_scan, algo="scan")
+            ex.sync()
+        ref_flops = [class_flops(st_scan, k, fs.n_sph) for k in range(3)]
     for _ in range(args.warmup):
         step(False)
-    agg = {k: 0 for k in ("rays", "ms0", "ms1", "ms2", "ms3", "f0", "f1", "f2", "l0", "l1", "l2", "l3")}
+    agg = {k: 0 for k in ("rays", "ms0", "ms1", "ms2", "ms3", "f0", "f1", "f2", "x0", "x1", "x2", "l0", "l1", "l2", "l3")}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -155,7 +184,8 @@ def main():
         for k in range(4):
             agg[f"ms{k}"] += st.kernel_ms[k]; agg[f"l{k}"] += st.launches[k]
         for k in range(3):
-            agg[f"f{k}"] += class_flops(st, k, fs.n_sph)
+            agg[f"f{k}"] += ref_flops[k] if ref_flops is not None else class_flops(st, k, fs.n_sph)
+            agg[f"x{k}"] += executed_flops(st, k, fs.n_sph)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -169,7 +199,25 @@ def main():
 
     if rank == 0:
         dom = max(range(3), key=lambda k: agg[f"ms{k}"])
-        ach = agg[f"f{dom}"] / max(agg[f"ms{dom}"], 1e-9) / 1e9          # TFLOP/s
+        names = KNAMES[algo]
+        tf = lambda f, ms: f / max(ms, 1e-9) / 1e9                       # FLOP, ms -> TFLOP/s
+        ach = tf(agg[f"f{dom}"], agg[f"ms{dom}"])
+        roof = {"bound": "valu", "kernel": f"{names[dom]} ({KLABEL[dom]})", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                "traffic": measured_traffic(names[dom], args.workload, args.algo),
+                "flop_model": "algorithmic work of the reference's linear scans: 44 FLOP per ray-triangle test + 25 per "
+                              "ray-sphere test, every primitive per closest-hit ray, up to the first occluder per shadow ray",
+                "avg_launch_ms": agg[f"ms{dom}"] / max(1, agg[f"l{dom}"]),
+                "kernel_ms_per_step": {f"{names[k]} ({KLABEL[k]})": agg[f"ms{k}"] / args.steps for k in range(4)},
+                "kernel_tflops": {f"{names[k]} ({KLABEL[k]})": tf(agg[f"f{k}"], agg[f"ms{k}"]) for k in range(3)}}
+        if algo == "bvh":
+            xa = tf(agg[f"x{dom}"], agg[f"ms{dom}"])
+            roof["executed"] = {"achieved": xa, "frac": xa / PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                                "flop_model": f"{F_NODE:.0f} FLOP per visited node + 44 per exact triangle test + 25 per sphere test, "
+                                              "as counted by the kernels"}
+            roof["note"] = ("frac > 1: the hierarchy proves most of the reference's tests unnecessary and never executes them; "
+                            "`executed` prices only the work the kernel did. --algo brute runs the reference's full scans "
+                            "(VALU-bound, frac ~ 1).")
         res = {
             "metric": "Mrays/sec (primary+secondary)", "value": rays_total / elapsed_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,15 +225,10 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "width": W, "height": H, "max_depth": depth, "triangles": fs.n_tri,
                        "spheres": fs.n_sph, "lamps": fs.n_lamp, "mode": "cpu-compat (ray_tracer.cpp semantics)",
+                       "algorithm": args.algo,
                        "partition": f"interleaved 8-row tiles over {world} GPU(s), gather to rank 0",
                        "rays_per_frame": rays_total / args.steps},
-            "roofline": {"bound": "valu", "kernel": KNAMES[dom], "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": measured_traffic(KNAMES[dom], args.workload),
-                         "flop_model": "44 FLOP per ray-triangle test + 25 per ray-sphere test, tests counted in the reference's scan order",
-                         "avg_launch_ms": agg[f"ms{dom}"] / max(1, agg[f"l{dom}"]),
-                         "kernel_ms_per_step": {KNAMES[k]: agg[f"ms{k}"] / args.steps for k in range(4)},
-                         "kernel_tflops": {KNAMES[k]: agg[f"f{k}"] / max(agg[f"ms{k}"], 1e-9) / 1e9 for k in range(3)}},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(fs, W, H, depth, args.cpu_budget)
