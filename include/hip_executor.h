@@ -152,6 +152,8 @@ typedef struct hipexec_stats {
                                      nodes visited, summed over rays (HIPEXEC_ALGO_BVH)            */
     uint64_t bvh_tests[3];        /* per ray class: exact ray-triangle tests evaluated, summed over
                                      rays (HIPEXEC_ALGO_BVH)                                       */
+    uint64_t bvh_stack_overflows; /* rays whose traversal stack overflowed and that were finished by a
+                                     linear scan instead (same result, slow); expected 0          */
     uint32_t algorithm;           /* HIPEXEC_ALGO_* the call ran with                             */
     uint32_t launches[HIPEXEC_K_COUNT];
     float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */

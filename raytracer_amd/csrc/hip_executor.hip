@@ -394,6 +394,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
         h->acc.bvh_nodes[k] = h->h_cnt64[8 + k]; h->acc.bvh_tests[k] = h->h_cnt64[11 + k];
     }
     h->acc.rays_shadow += h->h_cnt64[14];
+    h->acc.bvh_stack_overflows = h->h_cnt64[15];
     h->acc.algorithm = h->use_bvh ? HIPEXEC_ALGO_BVH : HIPEXEC_ALGO_SCAN;
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {

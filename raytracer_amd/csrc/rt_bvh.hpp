@@ -25,7 +25,7 @@ namespace rt {
 constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 4;
-constexpr int BVH_STACK = 32;                   // LDS stack entries per lane
+constexpr int BVH_STACK = 24;                   // LDS stack entries per lane
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
 constexpr float BVH_TIGHT = 4.0e-6f;
@@ -213,16 +213,21 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
 // In a box whose corners are at most qb (L1) from o, |q| <= qb and |e1|, |e2| <= 2 qb, so
 //   error <= 1.92e-6 * qb / (s c)                         ("tight", scale free)
 //   error <= 1.92e-2 * |d| |e1||e2| * qb                  ("loose", from |det| > 1e-4)
+// (qb per box rather than one bound per ray: shadow rays start on the surface, where the loose
+// form would otherwise enlarge the boxes next to the origin by the size of the whole scene)
 // Both are used with margin: A = BVH_LOOSE * max |e1||e2| over the subtree, and the tight form
 // with BVH_TIGHT when the normals of the subtree lie in a cone that keeps s*c >= 2e-3 for this
 // ray (g below is a lower bound of s*c / BVH_TIGHT).  E covers the rounding of the slab
-// arithmetic itself (each face moves by less than 2^-22 of the magnitudes involved).
+// arithmetic itself (each face moves by less than 2^-22 of |o| + |box coordinate|).  The
+// slab terms are formed as ((face - in) - o) * inv, never as face*inv - o*inv: with a zero
+// direction component inv is +-inf and only the first form keeps the sign of (face - o), so
+// that an origin between the two faces gives (-inf, +inf) on that axis.
 struct TRay { f3 o, inv, dhat; float dlen, E; };
 
 DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     TRay r;
     r.o = o;
-    r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);        // +-inf for zero components: handled by the slab test
+    r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.dlen = sqrtf(dot(d, d));
     float il = 1.0f / r.dlen;
     r.dhat = d * il;
@@ -254,29 +259,37 @@ DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float4 cone, float limit, 
 // cross(e2, e1) read from the record (the same operations on the same inputs) and
 // cross(e1, e2) taken as its negation (exact up to the sign of zeros, which cannot change
 // an accepted hit: a zero dett is rejected by both t thresholds).
+// Most candidates are misses, so each quotient is first bounded without dividing: with
+// a = |det| and the numerators multiplied by sign(det),
+//   dett <= T/2 * a          =>  fl(dett/det) <= T        (T = 1e-4 / 1e-3, rejected by t > T)
+//   detu <  -1e-30 * a       =>  fl(detu/det) < 0         (likewise detv)
+//   detu + detv > 1.00001 a  =>  fl(fl(u) + fl(v)) > 1
+// (margins far above the 2^-24 roundings, and a > 1e-4 keeps every product normal).  What is
+// not rejected this way is decided by the reference's own divisions and comparisons.
 template <int MODE>
 DEV bool tri_exact_rec(f3 o, f3 d, f3 p, f3 e1, f3 e2, f3 c21, float &t, float &u, float &v) {
     f3 q = o - p;
     float det = dot(d, c21);
+    float a = fabsf(det);
+    if (MODE == HIPEXEC_MODE_CL) { if (!(a > 0.001f)) return false; }
+    else if (a <= RT_EPSF) return false;
+    const bool neg = det < 0.0f;
+    float dett = dot(q, -c21);
+    if ((neg ? -dett : dett) <= (MODE == HIPEXEC_MODE_CL ? 0.0005f : 0.00005f) * a) return false;
+    float detu = dot(d, cross(e2, q));
+    if ((neg ? -detu : detu) < -1.0e-30f * a) return false;
+    float detv = dot(d, cross(q, e1));
+    if ((neg ? -detv : detv) < -1.0e-30f * a) return false;
+    if ((neg ? -(detu + detv) : (detu + detv)) > 1.00001f * a) return false;
+    float tt = dett / det, uu = detu / det, vv = detv / det;
     if (MODE == HIPEXEC_MODE_CL) {
-        float dett = dot(q, -c21);
-        float detu = dot(d, cross(e2, q));
-        float detv = dot(d, cross(q, e1));
-        float tt = dett / det, uu = detu / det, vv = detv / det;
         bool hit = (det > 0.001f || det < -0.001f);
         hit = hit && (tt > 0.001f);
         hit = hit && (uu > 0.0f && vv > 0.0f && uu + vv < 1.0f);
         t = tt; u = uu; v = vv;
         return hit;
     }
-    if (fabsf(det) <= RT_EPSF) return false;
-    float dett = dot(q, -c21);
-    float tt = dett / det;
     if (tt <= RT_EPSF) return false;
-    float detu = dot(d, cross(e2, q));
-    float detv = dot(d, cross(q, e1));
-    float uu = detu / det;
-    float vv = detv / det;
     if (uu < 0.0f || vv < 0.0f || vv + uu > 1.0f) return false;
     t = tt; u = uu; v = vv;
     return true;
@@ -301,7 +314,9 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
     bool overflow = false, found = false;
     const float4 *__restrict__ T = B.tris;
     while (node != BVH_NONE) {
-        if (!(node & BVH_LEAF)) {
+        // inner nodes until this lane holds a leaf (or is finished); the wave leaves the loop when
+        // every lane does, so the leaf code below runs with as many lanes as possible
+        while (!(node & BVH_LEAF) && node != BVH_NONE) {
             const float4 *N = B.nodes + 6 * (size_t)node;
             float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
             n_nodes++;
@@ -313,12 +328,13 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
                 uint32_t far = swap ? r0 : r1;
                 node = swap ? r1 : r0;
                 if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
-                else { overflow = true; break; }
+                else { overflow = true; node = BVH_NONE; }
             } else if (hit0) node = r0;
             else if (hit1) node = r1;
             else if (sp > 0) { sp--; node = stk[256 * sp]; }
             else node = BVH_NONE;
-        } else {
+        }
+        if (node != BVH_NONE) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
             for (uint32_t k = first; k < first + cnt; k++) {
                 float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
@@ -330,12 +346,13 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
                     limit = fminf(limit, best.t);
                 }
             }
-            if (ANY && found) break;
-            if (sp > 0) { sp--; node = stk[256 * sp]; }
+            if (ANY && found) node = BVH_NONE;
+            else if (sp > 0) { sp--; node = stk[256 * sp]; }
             else node = BVH_NONE;
         }
     }
     if (overflow) {
+        n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
         if (!ANY) best = best_none();
         for (uint32_t k = 0; k < B.n && !(ANY && found); k++) {
             float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
@@ -374,11 +391,13 @@ __global__ __launch_bounds__(256) void k_raygen(DScene S, Frame F, float4 *__res
 
 // counters[8 + klass] += nodes visited, counters[11 + klass] += exact triangle tests
 // (klass 0 camera rays, 1 other closest-hit rays, 2 shadow rays)
+// counters[15] += rays that overflowed the traversal stack (flagged in bit 31 of n_nodes)
 DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris) {
-    unsigned long long a = wave_sum_u64(n_nodes), b = wave_sum_u64(n_tris);
+    unsigned long long a = wave_sum_u64(n_nodes & 0x7fffffffu), b = wave_sum_u64(n_tris), c = wave_sum_u64(n_nodes >> 31);
     if ((threadIdx.x & 63u) == 0) {
         if (a) atomicAdd(&counters[8 + klass], a);
         if (b) atomicAdd(&counters[11 + klass], b);
+        if (c) atomicAdd(&counters[15], c);
     }
 }
 
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const floa
 // neighbouring surface points.  Occluded pairs set bit `lamp` of occl[s * lw + lamp / 32].
 // counters[14] += shadow rays traced.
 // ---------------------------------------------------------------------------------------
-constexpr int SH_LAMPS = 8;
+constexpr int SH_LAMPS = 4;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const float4 *__restrict__ rays,
