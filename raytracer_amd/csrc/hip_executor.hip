@@ -74,6 +74,8 @@ struct hipexec {
     bool bvh_ok = false;                      // a hierarchy exists for this scene
     bool bvh_default = true;                  // algorithm of calls that do not choose (HIPEXEC_ALGO=scan|bvh)
     bool use_bvh = false;                     // algorithm of the call in progress
+    int refill_closest = REFILL_BELOW, refill_shadow = SHP_REFILL_BELOW;   // HIPEXEC_REFILL_CLOSEST / HIPEXEC_REFILL_SHADOW
+    bool bvh_refill = true;                   // closest-hit kernel that refills idle lanes (HIPEXEC_BVH_REFILL=0: one ray per lane)
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;
     Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
@@ -452,6 +454,18 @@ int launch_anyhit_lamp(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t n
     }
 }
 
+template <int MODE>
+int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t n, float4 *hits, int klass_count)
+{
+    if (h->bvh_refill) {
+        uint32_t blocks = (n + CLOSEST_RAYS_PER_BLOCK - 1) / CLOSEST_RAYS_PER_BLOCK;
+        LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, h->refill_closest);
+    } else {
+        LAUNCH(klass_time, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count);
+    }
+    return HIPEXEC_OK;
+}
+
 template <int MODE, int R>
 int launch_closest_r(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 {
@@ -465,10 +479,7 @@ int launch_closest_r(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 template <int MODE>
 int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 {
-    if (h->use_bvh) {
-        LAUNCH(HIPEXEC_K_CLOSEST, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, 1);
-        return HIPEXEC_OK;
-    }
+    if (h->use_bvh) return launch_bvh_closest<MODE>(h, HIPEXEC_K_CLOSEST, rays, n, hits, 1);
     switch (h->closest_r) {
     case 1: return launch_closest_r<MODE, 1>(h, rays, n, hits);
     case 3: return launch_closest_r<MODE, 3>(h, rays, n, hits);
@@ -490,7 +501,12 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
     int level = 0;
     for (;; level++) {
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
-        if (S.n_lamp && h->use_bvh) {
+        // many lamps: shadow rays of open scenes are rarely cut short, refilling buys nothing and the
+        // one-pass kernel keeps more waves resident
+        if (S.n_lamp && h->use_bvh && h->bvh_refill && S.n_lamp <= (uint32_t)SHP_LAMPS) {
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow_p<MODE>), (n + SHP_SAMPLES - 1) / SHP_SAMPLES, S, h->B, cur_rays, cur_hits, n,
+                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, h->refill_shadow);
+        } else if (S.n_lamp && h->use_bvh) {
             LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), blocks_for(n), S, h->B, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
                    h->lamp_words, h->d_cnt64);
         } else if (S.n_lamp) {
@@ -580,8 +596,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         CHK(reserve_trace_buffers(h, n0, depth + 1));
         if (h->use_bvh) {
             LAUNCH(HIPEXEC_K_PRIMARY, (k_raygen<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>());
-            LAUNCH(HIPEXEC_K_PRIMARY, (k_bvh_closest<MODE>), blocks_for(n0), S, h->B, h->rayA.as<float4>(), (uint32_t)n0,
-                   h->hit0.as<float4>(), h->d_cnt64, 0);
+            CHK(launch_bvh_closest<MODE>(h, HIPEXEC_K_PRIMARY, h->rayA.as<float4>(), (uint32_t)n0, h->hit0.as<float4>(), 0));
         } else {
             LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>(), h->d_cnt64);
         }
@@ -669,6 +684,9 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) h->anyhit_lds = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
+        if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
+        if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = getenv("HIPEXEC_REFILL_SHADOW")) h->refill_shadow = std::max(1, std::min(64, atoi(e)));
         HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
         return build_scene(h, scene);
     }();

@@ -367,6 +367,155 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
     return found;
 }
 
+// ---------------------------------------------------------------------------------------
+// Burst form of the traversal for kernels that refill idle lanes: the lanes of a wave whose
+// `node` is not BVH_NONE advance until fewer than `min_active` of them are left, so that the
+// caller can hand new rays to the idle lanes before the wave runs mostly empty.
+// ---------------------------------------------------------------------------------------
+// The per-lane flags are 0/1 words on purpose: as `bool` the compiler keeps them as lane masks in
+// scalar registers, and with the loops below (wave-uniform exits, refills, spilled scalars) that
+// form lost updates on gfx950 (ROCm 7.2 hipcc); shadow rays then missed occluders.
+struct TState { uint32_t node; int sp; float limit; uint32_t found, overflow; };
+DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris);
+
+template <int MODE, bool ANY>
+DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &best, uint32_t *stk, int min_active,
+                   uint32_t &n_nodes, uint32_t &n_tris)
+{
+    const float4 *__restrict__ T = B.tris;
+    uint32_t node = st.node;
+    int sp = st.sp;
+    float limit = st.limit;
+    uint32_t found = st.found, overflow = st.overflow;
+    for (;;) {
+        while (!(node & BVH_LEAF) && node != BVH_NONE) {
+            const float4 *N = B.nodes + 6 * (size_t)node;
+            float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
+            n_nodes++;
+            float t0, t1;
+            bool hit0 = bvh_box(r, l0, h0, c0, limit, t0), hit1 = bvh_box(r, l1, h1, c1, limit, t1);
+            uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
+            if (hit0 && hit1) {
+                bool swap = t1 < t0;
+                uint32_t far = swap ? r0 : r1;
+                node = swap ? r1 : r0;
+                if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
+                else { overflow = 1u; node = BVH_NONE; }
+            } else if (hit0) node = r0;
+            else if (hit1) node = r1;
+            else if (sp > 0) { sp--; node = stk[256 * sp]; }
+            else node = BVH_NONE;
+        }
+        if (node != BVH_NONE) {
+            uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
+            for (uint32_t k = first; k < first + cnt; k++) {
+                if (ANY && found) continue;
+                float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
+                n_tris++;
+                float t, u, v;
+                if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
+                    if (ANY) found = 1u;
+                    else {
+                        best_update_indexed(best, t, u, v, (int)B.ids[k]);
+                        limit = fminf(limit, best.t);
+                    }
+                }
+            }
+            if (ANY && found) node = BVH_NONE;
+            else if (sp > 0) { sp--; node = stk[256 * sp]; }
+            else node = BVH_NONE;
+        }
+        unsigned long long act = __ballot(node != BVH_NONE);
+        if (act == 0 || __popcll(act) < min_active) break;
+    }
+    st.node = node; st.sp = sp; st.limit = limit; st.found = found; st.overflow = overflow;
+}
+
+// linear scan of all records: the answer for a ray whose traversal stack overflowed
+template <int MODE, bool ANY>
+DEV bool bvh_linear(const DBvh &B, f3 o, f3 d, Best &best, uint32_t &n_tris) {
+    const float4 *__restrict__ T = B.tris;
+    bool found = false;
+    if (!ANY) best = best_none();
+    for (uint32_t k = 0; k < B.n && !(ANY && found); k++) {
+        float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
+        n_tris++;
+        float t, u, v;
+        if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
+            if (ANY) found = true;
+            else best_update_indexed(best, t, u, v, (int)B.ids[k]);
+        }
+    }
+    return found;
+}
+
+// lanes with `want` get consecutive indices from the LDS counter *next (one LDS atomic per wave);
+// returns the first index past the ones handed out to this wave
+DEV uint32_t wave_take(bool want, uint32_t *next, uint32_t &idx) {
+    unsigned long long m = __ballot(want);
+    uint32_t cnt = (uint32_t)__popcll(m), start = 0;
+    int lane = lane_id();
+    if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) start = atomicAdd(next, cnt);
+        start = (uint32_t)__shfl((int)start, leader);
+    }
+    idx = start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    return start + cnt;
+}
+
+// Closest hit of n queued rays.  A block owns CLOSEST_RAYS_PER_BLOCK consecutive rays and its
+// lanes take them one at a time: a lane that finishes its ray writes the hit and fetches the
+// next ray of the block, so waves stay populated although rays differ widely in length.
+constexpr uint32_t CLOSEST_RAYS_PER_BLOCK = 2048;
+constexpr int REFILL_BELOW = 44;       // active lanes below which a wave goes back to fetch rays
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_closest_p(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+                                                       float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
+                                                       int klass, int refill_below)
+{
+    __shared__ uint32_t stack[BVH_STACK][256];
+    __shared__ uint32_t next;
+    const uint32_t base = blockIdx.x * CLOSEST_RAYS_PER_BLOCK;
+    const uint32_t end = min(n, base + CLOSEST_RAYS_PER_BLOCK);
+    if (threadIdx.x == 0) next = base;
+    __syncthreads();
+    uint32_t *stk = &stack[0][threadIdx.x];
+    uint32_t n_nodes = 0, n_tris = 0, j = 0;
+    uint32_t have = 0u;
+    f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
+    TRay r = tray_make(S, B, o, d);
+    TState st; st.node = BVH_NONE; st.sp = 0; st.limit = 0.f; st.found = 0u; st.overflow = 0u;
+    Best tb = best_none(), sb = best_none();
+    for (;;) {
+        bool idle = st.node == BVH_NONE;
+        if (idle && have) {
+            if (st.overflow) { bvh_linear<MODE, false>(B, o, d, tb, n_tris); n_nodes |= 0x80000000u; }
+            hits[j] = merge_hits<MODE>(S, tb, sb);
+            have = 0u;
+        }
+        uint32_t idx;
+        uint32_t past = wave_take(idle, &next, idx);
+        if (idle && idx < end) {
+            uint32_t s, aux;
+            load_ray(rays, idx, o, d, s, aux);
+            if (aux == 0u) {
+                j = idx; have = 1u;
+                sb = spheres_closest<MODE>(S, o, d);
+                tb = best_none();
+                r = tray_make(S, B, o, d);
+                st.node = B.root; st.sp = 0; st.found = 0u; st.overflow = 0u;
+                st.limit = sb.id >= 0 ? sb.t : __builtin_inff();
+            }
+        }
+        const bool more = past < end;
+        if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
+        bvh_burst<MODE, false>(B, r, o, d, st, tb, stk, more ? refill_below : 1, n_nodes, n_tris);
+    }
+    bvh_count(counters, klass, n_nodes, n_tris);
+}
+
 // camera rays of the pixel grid into ray records; sample s = r * n_slots + slot.  Slots
 // outside the frame get aux = 1 and a hit record with id -2, and are skipped by k_bvh_closest.
 template <int MODE>
@@ -547,6 +696,133 @@ __global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const floa
                 if (occluded) atomicOr(&occl[(size_t)sample_of[t2] * lw + (l >> 5)], 1u << (l & 31u));
                 n_rays++;
             }
+        }
+        __syncthreads();
+    }
+    bvh_count(counters, 2, n_nodes, n_tris);
+    unsigned long long nr = wave_sum_u64(n_rays);
+    if (lane == 0 && nr) atomicAdd(&counters[14], nr);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_shadow_p: as k_bvh_shadow, with a block owning SHP_SAMPLES rays of the level and its
+// lanes taking list entries one at a time (a lane whose shadow ray is decided fetches the next
+// entry), so waves stay populated although occluded rays end early.
+// ---------------------------------------------------------------------------------------
+constexpr int SHP_SUB = 2;                       // samples per thread
+constexpr int SHP_SAMPLES = 256 * SHP_SUB;
+constexpr int SHP_LAMPS = 4;                     // lamps per pass over the block's samples
+constexpr int SHP_REFILL_BELOW = 52;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_shadow_p(DScene S, DBvh B, const float4 *__restrict__ rays,
+                                                      const float4 *__restrict__ hits, uint32_t n,
+                                                      uint32_t *__restrict__ occl, uint32_t lw,
+                                                      unsigned long long *__restrict__ counters, int refill_below)
+{
+    constexpr int NCNT = SHP_LAMPS * SHP_SUB * 4;                 // (lamp, sub-batch, wave) counters, <= 64
+    static_assert(NCNT <= 64, "prefix sum runs in one wave");
+    __shared__ uint32_t stack[BVH_STACK][256];
+    __shared__ uint16_t list[SHP_LAMPS * SHP_SAMPLES];
+    __shared__ uint32_t wcnt[NCNT + 1];
+    __shared__ uint32_t next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)SHP_SAMPLES;
+    uint32_t *stk = &stack[0][tid];
+    f3 P[SHP_SUB], N[SHP_SUB]; float dotWithDir[SHP_SUB]; bool hit[SHP_SUB];
+#pragma unroll
+    for (int sub = 0; sub < SHP_SUB; sub++) {
+        uint32_t j = base + (uint32_t)sub * 256u + tid;
+        bool valid = j < n;
+        f3 o, d; uint32_t s, aux;
+        load_ray(rays, valid ? j : 0u, o, d, s, aux);
+        float4 h = hits[valid ? j : 0u];
+        hit[sub] = valid && __float_as_int(h.w) >= 0;
+        Surf sf;
+        if (hit[sub]) sf = surface(S, o, d, h, false);
+        else { sf.P = mk(0.f, 0.f, 0.f); sf.N = mk(0.f, 0.f, 1.f); }
+        P[sub] = sf.P; N[sub] = sf.N; dotWithDir[sub] = dot(d, sf.N);
+    }
+    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
+    for (uint32_t l0 = 0; l0 < S.n_lamp; l0 += SHP_LAMPS) {
+        unsigned long long votes[SHP_LAMPS][SHP_SUB];
+#pragma unroll
+        for (int li = 0; li < SHP_LAMPS; li++) {
+#pragma unroll
+            for (int sub = 0; sub < SHP_SUB; sub++) {
+                bool cast = false;
+                if (l0 + li < S.n_lamp) {
+                    float4 lp = S.lamp[l0 + li];
+                    f3 toLamp = xyz(lp) - P[sub];
+                    cast = hit[sub] && casts_shadow_ray<MODE>(dotWithDir[sub], dot(toLamp, N[sub]));
+                }
+                votes[li][sub] = __ballot(cast);
+                if (lane == 0) wcnt[(li * SHP_SUB + sub) * 4 + w] = (uint32_t)__popcll(votes[li][sub]);
+            }
+        }
+        if (tid == 0) next = 0;
+        __syncthreads();
+        if (tid < 64) {                     // exclusive prefix in (lamp, sub-batch, wave) order
+            uint32_t own = tid < NCNT ? wcnt[tid] : 0u, inc = own;
+            for (int off = 1; off < NCNT; off <<= 1) {
+                uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+                if ((int)lane >= off) inc += up;
+            }
+            uint32_t total = (uint32_t)__shfl((int)inc, NCNT - 1);
+            if (tid < NCNT) wcnt[tid] = inc - own;
+            if (tid == 0) wcnt[NCNT] = total;
+        }
+        __syncthreads();
+        const uint32_t total = wcnt[NCNT];
+#pragma unroll
+        for (int li = 0; li < SHP_LAMPS; li++) {
+#pragma unroll
+            for (int sub = 0; sub < SHP_SUB; sub++) {
+                if ((votes[li][sub] >> lane) & 1ull) {
+                    uint32_t pos = wcnt[(li * SHP_SUB + sub) * 4 + w] + (uint32_t)__popcll(votes[li][sub] & ((1ull << lane) - 1ull));
+                    list[pos] = (uint16_t)(((uint32_t)sub * 256u + tid) | ((uint32_t)li << 12));
+                }
+            }
+        }
+        __syncthreads();
+        // trace the list
+        TState st; st.node = BVH_NONE; st.sp = 0; st.limit = __builtin_inff(); st.found = 0u; st.overflow = 0u;
+        uint32_t have = 0u;
+        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
+        TRay r = tray_make(S, B, o, d);
+        Best none = best_none();
+        uint32_t word = 0, bit = 0;
+        for (;;) {
+            bool idle = st.node == BVH_NONE;
+            if (idle && have) {
+                if (st.overflow) { st.found = bvh_linear<MODE, true>(B, o, d, none, n_tris) ? 1u : 0u; n_nodes |= 0x80000000u; }
+                if (st.found) atomicOr(&occl[word], bit);
+                have = 0u;
+            }
+            uint32_t e;
+            uint32_t past = wave_take(idle, &next, e);
+            if (idle && e < total) {
+                uint32_t entry = list[e];
+                uint32_t j = base + (entry & 0x0fffu), l = l0 + (entry >> 12);
+                f3 ro, rd; uint32_t s, aux;
+                load_ray(rays, j, ro, rd, s, aux);
+                float4 h = hits[j];
+                o = ro + h.x * rd;                               // the hit point, as surface() computes it
+                float4 lp = S.lamp[l];
+                d = xyz(lp) - o;
+                word = s * lw + (l >> 5); bit = 1u << (l & 31u);
+                have = 1u; n_rays++;
+                st.found = 0u; st.overflow = 0u; st.sp = 0;
+                for (uint32_t k = 0; k < S.n_sph && !st.found; k++) {
+                    float4 sp = S.sph[k];
+                    float t;
+                    st.found = sph_exact<MODE>(o, d, xyz(sp), sp.w, t) ? 1u : 0u;
+                }
+                if (!st.found) { r = tray_make(S, B, o, d); st.node = B.root; }
+            }
+            const bool more = past < total;
+            if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
+            bvh_burst<MODE, true>(B, r, o, d, st, none, stk, more ? refill_below : 1, n_nodes, n_tris);
         }
         __syncthreads();
     }
