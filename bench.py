@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test
-F_NODE = 84.0                        # FLOP per visited hierarchy node (two enlarged-box slab tests, see bvh_box)
+F_NODE = 96.0                        # FLOP per visited hierarchy node (two enlarged-box slab tests, see bvh_box)
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA)
 
 WORKLOADS = {
@@ -34,7 +34,7 @@ WORKLOADS = {
 }
 
 KNAMES = {"scan": ["k_primary", "k_closest", "k_anyhit_lamp", "shade/resolve"],
-          "bvh": ["k_bvh_closest", "k_bvh_closest", "k_bvh_shadow", "shade/resolve"]}
+          "bvh": ["k_bvh_closest_p", "k_bvh_closest_p", "k_bvh_shadow_p", "shade/resolve"]}
 KLABEL = ["camera rays", "bounce rays", "shadow rays", "shading"]
 
 

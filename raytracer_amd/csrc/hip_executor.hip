@@ -682,13 +682,18 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
-        if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) h->anyhit_lds = atoi(e) != 0;
+        bool anyhit_lds_set = false;
+        if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) { h->anyhit_lds = atoi(e) != 0; anyhit_lds_set = true; }
         if (const char *e = getenv("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
         if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("HIPEXEC_REFILL_SHADOW")) h->refill_shadow = std::max(1, std::min(64, atoi(e)));
         HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
-        return build_scene(h, scene);
+        CHK(build_scene(h, scene));
+        // full scans stage the lamp records through LDS (measured faster); with chunk culling each
+        // wave reads only the chunks it needs and the scalar path wins
+        if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
+        return HIPEXEC_OK;
     }();
     if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
     *out = h;
