@@ -15,8 +15,10 @@
 //   k_bvh_split   binary radix tree over the sorted keys, one thread per internal node
 //                 (longest-common-prefix construction; every node knows its key range)
 //   k_bvh_refit   boxes bottom-up, second thread to arrive at a node computes it
-//   k_bvh_emit    traversal nodes: both child boxes in one 64-byte record; subtrees with at
-//                 most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
+//   k_bvh_emit    traversal nodes: both child boxes and normal cones in one 96-byte record;
+//                 subtrees with at most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
+// Frame kernels: k_raygen, k_bvh_closest_p, k_bvh_shadow_p (lanes refill from a per-block work
+// list); k_bvh_closest, k_bvh_anyhit, k_bvh_shadow are the one-ray-per-lane forms.
 #pragma once
 #include "rt_kernels.hpp"
 

@@ -11,8 +11,10 @@
 //                  bounce rays appended to the next level's queue (ballot/popcount)
 //   k_resolve      folds the per-level colours back to front, averages sub-samples, tone
 //                  curve, float4 RGBA store
-// All scans are brute force over every triangle like the reference; triangle records are
-// wave-uniform and reach the SIMDs through the scalar data path.
+// k_primary / k_closest / k_anyhit* are the index-order scan algorithm: triangles are visited in
+// the reference's order (optionally skipping 128-triangle chunks no ray of the wave can reach),
+// records are wave-uniform and reach the SIMDs through the scalar data path or LDS.  The default
+// algorithm, the hierarchy, lives in rt_bvh.hpp and shares k_shade / k_resolve with this file.
 #pragma once
 #include "rt_device.hpp"
 
