@@ -378,7 +378,7 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
 // scalar registers, and with the loops below (wave-uniform exits, refills, spilled scalars) that
 // form lost updates on gfx950 (ROCm 7.2 hipcc); shadow rays then missed occluders.
 struct TState { uint32_t node; int sp; float limit; uint32_t found, overflow; };
-DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris);
+DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris, uint32_t n_rays);
 
 template <int MODE, bool ANY>
 DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &best, uint32_t *stk, int min_active,
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_bvh_closest_p(DScene S, DBvh B, const f
         if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
         bvh_burst<MODE, false>(B, r, o, d, st, tb, stk, more ? refill_below : 1, n_nodes, n_tris);
     }
-    bvh_count(counters, klass, n_nodes, n_tris);
+    bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
 
 // camera rays of the pixel grid into ray records; sample s = r * n_slots + slot.  Slots
@@ -542,13 +542,27 @@ __global__ __launch_bounds__(256) void k_raygen(DScene S, Frame F, float4 *__res
 
 // counters[8 + klass] += nodes visited, counters[11 + klass] += exact triangle tests
 // (klass 0 camera rays, 1 other closest-hit rays, 2 shadow rays)
-// counters[15] += rays that overflowed the traversal stack (flagged in bit 31 of n_nodes)
-DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris) {
+// counters[15] += rays that overflowed the traversal stack (flagged in bit 31 of n_nodes).
+// Summed per wave, then per block in LDS, so a block issues at most three global atomics; every
+// thread of the block must call this (it contains barriers).
+DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris, uint32_t n_rays) {
+    __shared__ unsigned long long block_sum[4];
+    if (threadIdx.x < 4) block_sum[threadIdx.x] = 0ull;
+    __syncthreads();
     unsigned long long a = wave_sum_u64(n_nodes & 0x7fffffffu), b = wave_sum_u64(n_tris), c = wave_sum_u64(n_nodes >> 31);
+    unsigned long long r = wave_sum_u64(n_rays);
     if ((threadIdx.x & 63u) == 0) {
-        if (a) atomicAdd(&counters[8 + klass], a);
-        if (b) atomicAdd(&counters[11 + klass], b);
-        if (c) atomicAdd(&counters[15], c);
+        if (a) atomicAdd(&block_sum[0], a);
+        if (b) atomicAdd(&block_sum[1], b);
+        if (c) atomicAdd(&block_sum[2], c);
+        if (r) atomicAdd(&block_sum[3], r);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (block_sum[0]) atomicAdd(&counters[8 + klass], block_sum[0]);
+        if (block_sum[1]) atomicAdd(&counters[11 + klass], block_sum[1]);
+        if (block_sum[2]) atomicAdd(&counters[15], block_sum[2]);
+        if (block_sum[3]) atomicAdd(&counters[14], block_sum[3]);     // shadow rays traced without a queue
     }
 }
 
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(256) void k_bvh_closest(DScene S, DBvh B, const flo
         bvh_traverse<MODE, false>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris);
         hits[j] = merge_hits<MODE>(S, tb, sb);
     }
-    bvh_count(counters, klass, n_nodes, n_tris);
+    bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
 
 // occlusion of queued shadow rays: bit `lamp` of occl[s * lw + lamp / 32] is set for occluded rays
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const floa
         }
         if (occluded) atomicOr(&occl[(size_t)s * lw + (lamp >> 5)], 1u << (lamp & 31u));
     }
-    bvh_count(counters, 2, n_nodes, n_tris);
+    bvh_count(counters, 2, n_nodes, n_tris, 0u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -701,9 +715,7 @@ __global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const floa
         }
         __syncthreads();
     }
-    bvh_count(counters, 2, n_nodes, n_tris);
-    unsigned long long nr = wave_sum_u64(n_rays);
-    if (lane == 0 && nr) atomicAdd(&counters[14], nr);
+    bvh_count(counters, 2, n_nodes, n_tris, n_rays);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -828,9 +840,7 @@ __global__ __launch_bounds__(256) void k_bvh_shadow_p(DScene S, DBvh B, const fl
         }
         __syncthreads();
     }
-    bvh_count(counters, 2, n_nodes, n_tris);
-    unsigned long long nr = wave_sum_u64(n_rays);
-    if (lane == 0 && nr) atomicAdd(&counters[14], nr);
+    bvh_count(counters, 2, n_nodes, n_tris, n_rays);
 }
 
 }  // namespace rt

@@ -394,6 +394,25 @@ DEV uint32_t wave_append(bool pred, uint32_t *counter) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// The same for a whole 256-thread block: one global atomic per block instead of one per wave
+// (atomics on a single address are serialised by the L2; at one per wave they bound k_shade).
+// Every thread of the block must call this; `scratch` is 5 words of LDS.
+DEV uint32_t block_append(bool pred, uint32_t *counter, uint32_t *scratch) {
+    unsigned long long m = __ballot(pred);
+    int lane = lane_id();
+    uint32_t w = threadIdx.x >> 6;
+    if (lane == 0) scratch[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        scratch[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = scratch[4];
+    for (uint32_t k = 0; k < w; k++) base += scratch[k];
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 DEV unsigned long long wave_sum_u64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;   // valid in lane 0

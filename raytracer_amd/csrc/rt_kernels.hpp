@@ -882,7 +882,8 @@ __global__ __launch_bounds__(256) void k_shade(DScene S, const float4 *__restric
         for (uint32_t k = 0; k < lw; k++) occl[(size_t)s * lw + k] = 0u;
     }
     if (spawn) {
-        uint32_t pos = wave_append(bounce, next_count);
+        __shared__ uint32_t append_scratch[5];
+        uint32_t pos = block_append(bounce, next_count, append_scratch);
         if (bounce) store_ray(next_rays, pos, bo, bd, s, 0u);
     }
 }

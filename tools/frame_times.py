@@ -7,7 +7,7 @@ import numpy as np
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 W, H, depth, fs = {"c2": (1920, 1080, 3, scenegen.scene_c2), "c5": (3840, 2160, 0, scenegen.scene_c5),
-                   "c1": (640, 480, 0, scenegen.scene_c1), "c4": (1920, 1080, 0, scenegen.scene_c4)}[wl]
+                   "c1": (640, 480, 0, scenegen.scene_c1), "c3": (3840, 2160, 5, scenegen.scene_c2), "c4": (1920, 1080, 0, scenegen.scene_c4)}[wl]
 fs = fs().to_flat()
 ex = HipExecutor(fs, device=0)
 out = np.zeros((H, W, 3), np.float32)
