@@ -74,6 +74,7 @@ struct hipexec {
     bool bvh_ok = false;                      // a hierarchy exists for this scene
     bool bvh_default = true;                  // algorithm of calls that do not choose (HIPEXEC_ALGO=scan|bvh)
     bool use_bvh = false;                     // algorithm of the call in progress
+    int sched_w = 8;                          // step scheduling weight of bvh_burst (HIPEXEC_SCHED_W), in eighths
     int refill_closest = REFILL_BELOW, refill_shadow = SHP_REFILL_BELOW;   // HIPEXEC_REFILL_CLOSEST / HIPEXEC_REFILL_SHADOW
     bool bvh_refill = true;                   // closest-hit kernel that refills idle lanes (HIPEXEC_BVH_REFILL=0: one ray per lane)
     uint32_t lamp_words = 1;
@@ -459,7 +460,7 @@ int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t 
 {
     if (h->bvh_refill) {
         uint32_t blocks = (n + CLOSEST_RAYS_PER_BLOCK - 1) / CLOSEST_RAYS_PER_BLOCK;
-        LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, h->refill_closest);
+        LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, h->refill_closest | (h->sched_w << 8));
     } else {
         LAUNCH(klass_time, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count);
     }
@@ -505,7 +506,7 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
         // one-pass kernel keeps more waves resident
         if (S.n_lamp && h->use_bvh && h->bvh_refill && S.n_lamp <= (uint32_t)SHP_LAMPS) {
             LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow_p<MODE>), (n + SHP_SAMPLES - 1) / SHP_SAMPLES, S, h->B, cur_rays, cur_hits, n,
-                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, h->refill_shadow);
+                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, h->refill_shadow | (h->sched_w << 8));
         } else if (S.n_lamp && h->use_bvh) {
             LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), blocks_for(n), S, h->B, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
                    h->lamp_words, h->d_cnt64);
@@ -688,6 +689,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("HIPEXEC_REFILL_SHADOW")) h->refill_shadow = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
         HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
         CHK(build_scene(h, scene));
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each

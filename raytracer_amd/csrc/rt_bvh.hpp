@@ -302,73 +302,6 @@ DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
     if (b.id < 0 || t < b.t || (t == b.t && id < b.id)) { b.t = t; b.u = u; b.v = v; b.id = id; }
 }
 
-// One ray per lane.  ANY = false: closest triangle hit into `best` (limit = largest t still of
-// interest, e.g. the sphere winner).  ANY = true: returns at the first accepted hit.
-// `stk` points at this lane's column of the LDS stack (entries 256 words apart).  A ray whose
-// stack would overflow is finished by a linear scan of all records, which gives the same
-// answer.
-template <int MODE, bool ANY>
-DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Best &best, uint32_t *stk,
-                      uint32_t &n_nodes, uint32_t &n_tris)
-{
-    uint32_t node = B.root;
-    int sp = 0;
-    bool overflow = false, found = false;
-    const float4 *__restrict__ T = B.tris;
-    while (node != BVH_NONE) {
-        // inner nodes until this lane holds a leaf (or is finished); the wave leaves the loop when
-        // every lane does, so the leaf code below runs with as many lanes as possible
-        while (!(node & BVH_LEAF) && node != BVH_NONE) {
-            const float4 *N = B.nodes + 6 * (size_t)node;
-            float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
-            n_nodes++;
-            float t0, t1;
-            bool hit0 = bvh_box(r, l0, h0, c0, limit, t0), hit1 = bvh_box(r, l1, h1, c1, limit, t1);
-            uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
-            if (hit0 && hit1) {
-                bool swap = t1 < t0;
-                uint32_t far = swap ? r0 : r1;
-                node = swap ? r1 : r0;
-                if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
-                else { overflow = true; node = BVH_NONE; }
-            } else if (hit0) node = r0;
-            else if (hit1) node = r1;
-            else if (sp > 0) { sp--; node = stk[256 * sp]; }
-            else node = BVH_NONE;
-        }
-        if (node != BVH_NONE) {
-            uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
-            for (uint32_t k = first; k < first + cnt; k++) {
-                float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
-                n_tris++;
-                float t, u, v;
-                if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
-                    if (ANY) { found = true; break; }
-                    best_update_indexed(best, t, u, v, (int)B.ids[k]);
-                    limit = fminf(limit, best.t);
-                }
-            }
-            if (ANY && found) node = BVH_NONE;
-            else if (sp > 0) { sp--; node = stk[256 * sp]; }
-            else node = BVH_NONE;
-        }
-    }
-    if (overflow) {
-        n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
-        if (!ANY) best = best_none();
-        for (uint32_t k = 0; k < B.n && !(ANY && found); k++) {
-            float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
-            n_tris++;
-            float t, u, v;
-            if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
-                if (ANY) found = true;
-                else best_update_indexed(best, t, u, v, (int)B.ids[k]);
-            }
-        }
-    }
-    return found;
-}
-
 // ---------------------------------------------------------------------------------------
 // Burst form of the traversal for kernels that refill idle lanes: the lanes of a wave whose
 // `node` is not BVH_NONE advance until fewer than `min_active` of them are left, so that the
@@ -380,9 +313,13 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
 struct TState { uint32_t node; int sp; float limit; uint32_t found, overflow; };
 DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris, uint32_t n_rays);
 
+// Every iteration the wave takes ONE of two steps, whichever more of its lanes are waiting for:
+// the inner-node step (two box tests, push/pop) or the leaf step (exact tests).  Lanes waiting for
+// the other kind sit the iteration out.  (`sched` = 0 selects the classic while-while order instead:
+// inner nodes until no lane has one, then leaves.)
 template <int MODE, bool ANY>
 DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &best, uint32_t *stk, int min_active,
-                   uint32_t &n_nodes, uint32_t &n_tris)
+                   uint32_t &n_nodes, uint32_t &n_tris, int sched = 8)
 {
     const float4 *__restrict__ T = B.tris;
     uint32_t node = st.node;
@@ -390,25 +327,31 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
     float limit = st.limit;
     uint32_t found = st.found, overflow = st.overflow;
     for (;;) {
-        while (!(node & BVH_LEAF) && node != BVH_NONE) {
-            const float4 *N = B.nodes + 6 * (size_t)node;
-            float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
-            n_nodes++;
-            float t0, t1;
-            bool hit0 = bvh_box(r, l0, h0, c0, limit, t0), hit1 = bvh_box(r, l1, h1, c1, limit, t1);
-            uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
-            if (hit0 && hit1) {
-                bool swap = t1 < t0;
-                uint32_t far = swap ? r0 : r1;
-                node = swap ? r1 : r0;
-                if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
-                else { overflow = 1u; node = BVH_NONE; }
-            } else if (hit0) node = r0;
-            else if (hit1) node = r1;
-            else if (sp > 0) { sp--; node = stk[256 * sp]; }
-            else node = BVH_NONE;
-        }
-        if (node != BVH_NONE) {
+        const bool at_leaf = (node & BVH_LEAF) != 0u;                    // BVH_NONE has the bit clear
+        const bool at_inner = !at_leaf && node != BVH_NONE;
+        const int n_inner = __popcll(__ballot(at_inner)), n_leaf = __popcll(__ballot(at_leaf));
+        if (n_inner + n_leaf == 0 || n_inner + n_leaf < min_active) break;
+        const bool inner_step = sched ? (n_inner * 8 >= n_leaf * sched) : (n_inner > 0);
+        if (inner_step) {
+            if (at_inner) {
+                const float4 *N = B.nodes + 6 * (size_t)node;
+                float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
+                n_nodes++;
+                float t0, t1;
+                bool hit0 = bvh_box(r, l0, h0, c0, limit, t0), hit1 = bvh_box(r, l1, h1, c1, limit, t1);
+                uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
+                if (hit0 && hit1) {
+                    bool swap = t1 < t0;
+                    uint32_t far = swap ? r0 : r1;
+                    node = swap ? r1 : r0;
+                    if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
+                    else { overflow = 1u; node = BVH_NONE; }
+                } else if (hit0) node = r0;
+                else if (hit1) node = r1;
+                else if (sp > 0) { sp--; node = stk[256 * sp]; }
+                else node = BVH_NONE;
+            }
+        } else if (at_leaf) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
             for (uint32_t k = first; k < first + cnt; k++) {
                 if (ANY && found) continue;
@@ -427,8 +370,6 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             else if (sp > 0) { sp--; node = stk[256 * sp]; }
             else node = BVH_NONE;
         }
-        unsigned long long act = __ballot(node != BVH_NONE);
-        if (act == 0 || __popcll(act) < min_active) break;
     }
     st.node = node; st.sp = sp; st.limit = limit; st.found = found; st.overflow = overflow;
 }
@@ -449,6 +390,22 @@ DEV bool bvh_linear(const DBvh &B, f3 o, f3 d, Best &best, uint32_t &n_tris) {
         }
     }
     return found;
+}
+
+// One ray per lane, start to finish.  ANY = false: closest triangle hit into `best` (limit =
+// largest t still of interest, e.g. the sphere winner).  ANY = true: returns whether any triangle
+// is hit.  `stk` points at this lane's column of the LDS stack (entries 256 words apart).
+template <int MODE, bool ANY>
+DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Best &best, uint32_t *stk,
+                      uint32_t &n_nodes, uint32_t &n_tris)
+{
+    TState st; st.node = B.root; st.sp = 0; st.limit = limit; st.found = 0u; st.overflow = 0u;
+    bvh_burst<MODE, ANY>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris);
+    if (st.overflow) {
+        n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
+        st.found = bvh_linear<MODE, ANY>(B, o, d, best, n_tris) ? 1u : 0u;
+    }
+    return st.found != 0u;
 }
 
 // lanes with `want` get consecutive indices from the LDS counter *next (one LDS atomic per wave);
@@ -513,7 +470,7 @@ __global__ __launch_bounds__(256) void k_bvh_closest_p(DScene S, DBvh B, const f
         }
         const bool more = past < end;
         if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
-        bvh_burst<MODE, false>(B, r, o, d, st, tb, stk, more ? refill_below : 1, n_nodes, n_tris);
+        bvh_burst<MODE, false>(B, r, o, d, st, tb, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, refill_below >> 8);
     }
     bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
@@ -836,7 +793,7 @@ __global__ __launch_bounds__(256) void k_bvh_shadow_p(DScene S, DBvh B, const fl
             }
             const bool more = past < total;
             if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
-            bvh_burst<MODE, true>(B, r, o, d, st, none, stk, more ? refill_below : 1, n_nodes, n_tris);
+            bvh_burst<MODE, true>(B, r, o, d, st, none, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, refill_below >> 8);
         }
         __syncthreads();
     }
