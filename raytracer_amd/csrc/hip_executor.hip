@@ -180,7 +180,9 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
         float ext[3];
         for (int k = 0; k < 3; k++) ext[k] = (float)(hi[k] - lo[k]);
-        inv.x = ext[0] > 0.f ? 1.0f / ext[0] : 0.f; inv.y = ext[1] > 0.f ? 1.0f / ext[1] : 0.f; inv.z = ext[2] > 0.f ? 1.0f / ext[2] : 0.f;
+        // cubic Morton cells (one scale for all axes): a flat scene then spends no split on its thin axis
+        float emax = std::max(ext[0], std::max(ext[1], ext[2]));
+        inv.x = inv.y = inv.z = emax > 0.f ? 1.0f / emax : 0.f;
         const dim3 blk(256), grid((n + 255) / 256);
         hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
         HIPCHK(hipGetLastError());

@@ -26,7 +26,7 @@ namespace rt {
 
 constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
-constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_LEAF_MAX = 2;
 constexpr int BVH_STACK = 24;                   // LDS stack entries per lane
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
