@@ -74,6 +74,7 @@ struct hipexec {
     bool bvh_ok = false;                      // a hierarchy exists for this scene
     bool bvh_default = true;                  // algorithm of calls that do not choose (HIPEXEC_ALGO=scan|bvh)
     bool use_bvh = false;                     // algorithm of the call in progress
+    int closest_per_block = 0;                // rays owned by a block of k_bvh_closest_p; 0 = by ray class (HIPEXEC_CLOSEST_PER_BLOCK)
     int sched_w = 8;                          // step scheduling weight of bvh_burst (HIPEXEC_SCHED_W), in eighths
     int refill_closest = REFILL_BELOW, refill_shadow = SHP_REFILL_BELOW;   // HIPEXEC_REFILL_CLOSEST / HIPEXEC_REFILL_SHADOW
     bool bvh_refill = true;                   // closest-hit kernel that refills idle lanes (HIPEXEC_BVH_REFILL=0: one ray per lane)
@@ -461,8 +462,11 @@ template <int MODE>
 int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t n, float4 *hits, int klass_count)
 {
     if (h->bvh_refill) {
-        uint32_t blocks = (n + CLOSEST_RAYS_PER_BLOCK - 1) / CLOSEST_RAYS_PER_BLOCK;
-        LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, h->refill_closest | (h->sched_w << 8));
+        // camera rays arrive in coherent 8x8 tiles (one ray per lane is best), bounce rays vary widely in length
+        uint32_t per_block = h->closest_per_block ? (uint32_t)h->closest_per_block : (klass_count == 0 ? 256u : 768u);
+        uint32_t blocks = (n + per_block - 1) / per_block;
+        LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count,
+               h->refill_closest | (h->sched_w << 8) | (int)(per_block << 16));
     } else {
         LAUNCH(klass_time, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count);
     }
@@ -691,6 +695,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("HIPEXEC_REFILL_SHADOW")) h->refill_shadow = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = getenv("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
         if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
         HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
         CHK(build_scene(h, scene));

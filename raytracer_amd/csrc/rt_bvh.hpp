@@ -423,10 +423,9 @@ DEV uint32_t wave_take(bool want, uint32_t *next, uint32_t &idx) {
     return start + cnt;
 }
 
-// Closest hit of n queued rays.  A block owns CLOSEST_RAYS_PER_BLOCK consecutive rays and its
+// Closest hit of n queued rays.  A block owns `per_block` consecutive rays (bits 16.. of the last argument) and its
 // lanes take them one at a time: a lane that finishes its ray writes the hit and fetches the
 // next ray of the block, so waves stay populated although rays differ widely in length.
-constexpr uint32_t CLOSEST_RAYS_PER_BLOCK = 2048;
 constexpr int REFILL_BELOW = 44;       // active lanes below which a wave goes back to fetch rays
 
 template <int MODE>
@@ -436,8 +435,9 @@ __global__ __launch_bounds__(256) void k_bvh_closest_p(DScene S, DBvh B, const f
 {
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ uint32_t next;
-    const uint32_t base = blockIdx.x * CLOSEST_RAYS_PER_BLOCK;
-    const uint32_t end = min(n, base + CLOSEST_RAYS_PER_BLOCK);
+    const uint32_t per_block = (uint32_t)refill_below >> 16;          // rays owned by a block
+    const uint32_t base = blockIdx.x * per_block;
+    const uint32_t end = min(n, base + per_block);
     if (threadIdx.x == 0) next = base;
     __syncthreads();
     uint32_t *stk = &stack[0][threadIdx.x];
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_bvh_closest_p(DScene S, DBvh B, const f
         }
         const bool more = past < end;
         if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
-        bvh_burst<MODE, false>(B, r, o, d, st, tb, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, refill_below >> 8);
+        bvh_burst<MODE, false>(B, r, o, d, st, tb, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, (refill_below >> 8) & 255);
     }
     bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_bvh_shadow_p(DScene S, DBvh B, const fl
             }
             const bool more = past < total;
             if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
-            bvh_burst<MODE, true>(B, r, o, d, st, none, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, refill_below >> 8);
+            bvh_burst<MODE, true>(B, r, o, d, st, none, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, (refill_below >> 8) & 255);
         }
         __syncthreads();
     }
