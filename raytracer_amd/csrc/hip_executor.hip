@@ -76,7 +76,7 @@ struct hipexec {
     bool use_bvh = false;                     // algorithm of the call in progress
     int closest_per_block = 0;                // rays owned by a block of k_bvh_closest_p; 0 = by ray class (HIPEXEC_CLOSEST_PER_BLOCK)
     int sched_w = 8;                          // step scheduling weight of bvh_burst (HIPEXEC_SCHED_W), in eighths
-    int refill_closest = REFILL_BELOW, refill_shadow = SHP_REFILL_BELOW;   // HIPEXEC_REFILL_CLOSEST / HIPEXEC_REFILL_SHADOW
+    int refill_closest = REFILL_BELOW;        // HIPEXEC_REFILL_CLOSEST: live lanes below which a wave fetches new rays
     bool bvh_refill = true;                   // closest-hit kernel that refills idle lanes (HIPEXEC_BVH_REFILL=0: one ray per lane)
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;
@@ -508,12 +508,7 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
     int level = 0;
     for (;; level++) {
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
-        // many lamps: shadow rays of open scenes are rarely cut short, refilling buys nothing and the
-        // one-pass kernel keeps more waves resident
-        if (S.n_lamp && h->use_bvh && h->bvh_refill && S.n_lamp <= (uint32_t)SHP_LAMPS) {
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow_p<MODE>), (n + SHP_SAMPLES - 1) / SHP_SAMPLES, S, h->B, cur_rays, cur_hits, n,
-                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, h->refill_shadow | (h->sched_w << 8));
-        } else if (S.n_lamp && h->use_bvh) {
+        if (S.n_lamp && h->use_bvh) {
             LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), blocks_for(n), S, h->B, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
                    h->lamp_words, h->d_cnt64);
         } else if (S.n_lamp) {
@@ -694,7 +689,6 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
         if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
-        if (const char *e = getenv("HIPEXEC_REFILL_SHADOW")) h->refill_shadow = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
         if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
         HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));

@@ -17,8 +17,9 @@
 //   k_bvh_refit   boxes bottom-up, second thread to arrive at a node computes it
 //   k_bvh_emit    traversal nodes: both child boxes and normal cones in one 96-byte record;
 //                 subtrees with at most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
-// Frame kernels: k_raygen, k_bvh_closest_p, k_bvh_shadow_p (lanes refill from a per-block work
-// list); k_bvh_closest, k_bvh_anyhit, k_bvh_shadow are the one-ray-per-lane forms.
+// Frame kernels: k_raygen, k_bvh_closest_p (lanes take the next ray of their block when theirs is
+// decided), k_bvh_shadow (shadow rays compacted per block in LDS); k_bvh_closest and k_bvh_anyhit
+// are the plain one-ray-per-lane forms used by the batch entry points and for A/B runs.
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -669,131 +670,6 @@ __global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const floa
                 if (occluded) atomicOr(&occl[(size_t)sample_of[t2] * lw + (l >> 5)], 1u << (l & 31u));
                 n_rays++;
             }
-        }
-        __syncthreads();
-    }
-    bvh_count(counters, 2, n_nodes, n_tris, n_rays);
-}
-
-// ---------------------------------------------------------------------------------------
-// k_bvh_shadow_p: as k_bvh_shadow, with a block owning SHP_SAMPLES rays of the level and its
-// lanes taking list entries one at a time (a lane whose shadow ray is decided fetches the next
-// entry), so waves stay populated although occluded rays end early.
-// ---------------------------------------------------------------------------------------
-constexpr int SHP_SUB = 2;                       // samples per thread
-constexpr int SHP_SAMPLES = 256 * SHP_SUB;
-constexpr int SHP_LAMPS = 4;                     // lamps per pass over the block's samples
-constexpr int SHP_REFILL_BELOW = 52;
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bvh_shadow_p(DScene S, DBvh B, const float4 *__restrict__ rays,
-                                                      const float4 *__restrict__ hits, uint32_t n,
-                                                      uint32_t *__restrict__ occl, uint32_t lw,
-                                                      unsigned long long *__restrict__ counters, int refill_below)
-{
-    constexpr int NCNT = SHP_LAMPS * SHP_SUB * 4;                 // (lamp, sub-batch, wave) counters, <= 64
-    static_assert(NCNT <= 64, "prefix sum runs in one wave");
-    __shared__ uint32_t stack[BVH_STACK][256];
-    __shared__ uint16_t list[SHP_LAMPS * SHP_SAMPLES];
-    __shared__ uint32_t wcnt[NCNT + 1];
-    __shared__ uint32_t next;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t base = blockIdx.x * (uint32_t)SHP_SAMPLES;
-    uint32_t *stk = &stack[0][tid];
-    f3 P[SHP_SUB], N[SHP_SUB]; float dotWithDir[SHP_SUB]; bool hit[SHP_SUB];
-#pragma unroll
-    for (int sub = 0; sub < SHP_SUB; sub++) {
-        uint32_t j = base + (uint32_t)sub * 256u + tid;
-        bool valid = j < n;
-        f3 o, d; uint32_t s, aux;
-        load_ray(rays, valid ? j : 0u, o, d, s, aux);
-        float4 h = hits[valid ? j : 0u];
-        hit[sub] = valid && __float_as_int(h.w) >= 0;
-        Surf sf;
-        if (hit[sub]) sf = surface(S, o, d, h, false);
-        else { sf.P = mk(0.f, 0.f, 0.f); sf.N = mk(0.f, 0.f, 1.f); }
-        P[sub] = sf.P; N[sub] = sf.N; dotWithDir[sub] = dot(d, sf.N);
-    }
-    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
-    for (uint32_t l0 = 0; l0 < S.n_lamp; l0 += SHP_LAMPS) {
-        unsigned long long votes[SHP_LAMPS][SHP_SUB];
-#pragma unroll
-        for (int li = 0; li < SHP_LAMPS; li++) {
-#pragma unroll
-            for (int sub = 0; sub < SHP_SUB; sub++) {
-                bool cast = false;
-                if (l0 + li < S.n_lamp) {
-                    float4 lp = S.lamp[l0 + li];
-                    f3 toLamp = xyz(lp) - P[sub];
-                    cast = hit[sub] && casts_shadow_ray<MODE>(dotWithDir[sub], dot(toLamp, N[sub]));
-                }
-                votes[li][sub] = __ballot(cast);
-                if (lane == 0) wcnt[(li * SHP_SUB + sub) * 4 + w] = (uint32_t)__popcll(votes[li][sub]);
-            }
-        }
-        if (tid == 0) next = 0;
-        __syncthreads();
-        if (tid < 64) {                     // exclusive prefix in (lamp, sub-batch, wave) order
-            uint32_t own = tid < NCNT ? wcnt[tid] : 0u, inc = own;
-            for (int off = 1; off < NCNT; off <<= 1) {
-                uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-                if ((int)lane >= off) inc += up;
-            }
-            uint32_t total = (uint32_t)__shfl((int)inc, NCNT - 1);
-            if (tid < NCNT) wcnt[tid] = inc - own;
-            if (tid == 0) wcnt[NCNT] = total;
-        }
-        __syncthreads();
-        const uint32_t total = wcnt[NCNT];
-#pragma unroll
-        for (int li = 0; li < SHP_LAMPS; li++) {
-#pragma unroll
-            for (int sub = 0; sub < SHP_SUB; sub++) {
-                if ((votes[li][sub] >> lane) & 1ull) {
-                    uint32_t pos = wcnt[(li * SHP_SUB + sub) * 4 + w] + (uint32_t)__popcll(votes[li][sub] & ((1ull << lane) - 1ull));
-                    list[pos] = (uint16_t)(((uint32_t)sub * 256u + tid) | ((uint32_t)li << 12));
-                }
-            }
-        }
-        __syncthreads();
-        // trace the list
-        TState st; st.node = BVH_NONE; st.sp = 0; st.limit = __builtin_inff(); st.found = 0u; st.overflow = 0u;
-        uint32_t have = 0u;
-        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
-        TRay r = tray_make(S, B, o, d);
-        Best none = best_none();
-        uint32_t word = 0, bit = 0;
-        for (;;) {
-            bool idle = st.node == BVH_NONE;
-            if (idle && have) {
-                if (st.overflow) { st.found = bvh_linear<MODE, true>(B, o, d, none, n_tris) ? 1u : 0u; n_nodes |= 0x80000000u; }
-                if (st.found) atomicOr(&occl[word], bit);
-                have = 0u;
-            }
-            uint32_t e;
-            uint32_t past = wave_take(idle, &next, e);
-            if (idle && e < total) {
-                uint32_t entry = list[e];
-                uint32_t j = base + (entry & 0x0fffu), l = l0 + (entry >> 12);
-                f3 ro, rd; uint32_t s, aux;
-                load_ray(rays, j, ro, rd, s, aux);
-                float4 h = hits[j];
-                o = ro + h.x * rd;                               // the hit point, as surface() computes it
-                float4 lp = S.lamp[l];
-                d = xyz(lp) - o;
-                word = s * lw + (l >> 5); bit = 1u << (l & 31u);
-                have = 1u; n_rays++;
-                st.found = 0u; st.overflow = 0u; st.sp = 0;
-                for (uint32_t k = 0; k < S.n_sph && !st.found; k++) {
-                    float4 sp = S.sph[k];
-                    float t;
-                    st.found = sph_exact<MODE>(o, d, xyz(sp), sp.w, t) ? 1u : 0u;
-                }
-                if (!st.found) { r = tray_make(S, B, o, d); st.node = B.root; }
-            }
-            const bool more = past < total;
-            if (__ballot(st.node != BVH_NONE || have) == 0 && !more) break;
-            bvh_burst<MODE, true>(B, r, o, d, st, none, stk, more ? (refill_below & 127) : 1, n_nodes, n_tris, (refill_below >> 8) & 255);
         }
         __syncthreads();
     }
