@@ -150,6 +150,8 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     DBvh &B = h->B;
     const uint32_t n = S.n_tri;
     B.n = n; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
+    B.stack_limit = BVH_STACK;
+    if (const char *e = getenv("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
     B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
     h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;

@@ -41,6 +41,7 @@ struct DBvh {
     uint32_t root;          // reference of the root (BVH_NONE for an empty scene)
     uint32_t n;             // triangles
     float scene_mag;        // bound on |coordinate| of any box corner
+    int stack_limit;        // usable entries of the traversal stack, <= BVH_STACK (lowered only to test the overflow path)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -345,7 +346,7 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
                     bool swap = t1 < t0;
                     uint32_t far = swap ? r0 : r1;
                     node = swap ? r1 : r0;
-                    if (sp < BVH_STACK) { stk[256 * sp] = far; sp++; }
+                    if (sp < B.stack_limit) { stk[256 * sp] = far; sp++; }
                     else { overflow = 1u; node = BVH_NONE; }
                 } else if (hit0) node = r0;
                 else if (hit1) node = r1;

@@ -147,3 +147,87 @@ def test_accelerations_do_not_change_results(soup):
                 assert np.array_equal(x, y)
         # culling really was active in the first configuration and off in the third
         assert sum(per[0][5]) < sum(per[2][5])
+
+
+def _nested_scene(n_levels=30, L=4.0):
+    """Large, mutually overlapping triangles whose centroids sit at 2^-k fractions of the scene cube:
+    the Morton tree peels one triangle per level, so it is about n_levels deep, and a ray through
+    the middle enters both children at every level -- deeper than the LDS traversal stack."""
+    from raytracer_amd.scene import FlatScene, normalize_f32, cross_f32
+    ext = 2 * L + 1.0
+    cents = []
+    for k in range(n_levels):
+        c = np.zeros(3)
+        c[k % 3] = ext * 2.0 ** -(k // 3 + 1)
+        cents.append(c - L)
+    cents.append(np.zeros(3) - L)
+    cents = np.asarray(cents)
+    n = cents.shape[0]
+    rng = np.random.default_rng(4)
+    tilt = rng.uniform(-0.3, 0.3, (n, 2))
+    p = np.zeros((n, 3), np.float32); e1 = np.zeros((n, 3), np.float32); e2 = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        a = np.array([-L, -L, tilt[i, 0]]); b = np.array([L, -L, tilt[i, 1]]); c = np.array([0.0, 2 * L, -tilt[i, 0] - tilt[i, 1]])
+        shift = cents[i] - (a + b + c) / 3.0 + np.array([0, 0, 0.0])
+        a, b, c = a + shift, b + shift, c + shift
+        p[i] = a; e1[i] = b - a; e2[i] = c - a
+    fs = FlatScene()
+    fs.tri_p, fs.tri_e1, fs.tri_e2 = p, e1, e2
+    fs.tri_norm = normalize_f32(cross_f32(e1, e2))
+    fs.tri_uv = np.zeros((n, 6), np.float32); fs.tri_mat = np.zeros((n,), np.int32)
+    fs.mat_color = [[0.7, 0.6, 0.5]]; fs.mat_kd = [0.8]; fs.mat_ks = [0.3]; fs.mat_hard = [20.0]; fs.mat_kr = [0.3]
+    fs.mat_tex = np.asarray([-1], np.int32)
+    fs.lamp_pos = [[2, 3, 20]]; fs.lamp_intensity = [1.0]; fs.lamp_distance = [30.0]
+    fs.cam_pos = np.asarray([0.3, 0.2, 25.0], np.float32)
+    return fs.normalised()
+
+
+def test_stack_overflow_falls_back_to_the_same_answer():
+    """Rays that outgrow the traversal stack are finished by a linear scan; results must not change.
+    The stack is shortened to 3 entries through the executor's test hook so that most rays overflow."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    from tests.util import ulp_diff
+    saved = os.environ.get("HIPEXEC_BVH_STACK_LIMIT")
+    os.environ["HIPEXEC_BVH_STACK_LIMIT"] = "3"
+    try:
+        for fs in (_nested_scene(), scenegen.small_variant("c2").to_flat(), scenegen.small_variant("soup").to_flat()):
+            rays = _adversarial_rays(fs, 13, n_each=120)
+            orc = Oracle(fs)
+            with HipExecutor(fs, device=0) as ex:
+                for mode in (CPU, CL):
+                    ref = orc.closest_hits(rays, mode)
+                    got = ex.closest_hits(rays, mode)
+                    assert np.array_equal(got["id"], ref["id"])
+                    assert np.array_equal(got["t"].view(np.int32), ref["t"].view(np.int32))
+                    assert np.array_equal(ex.any_hits(rays, mode) != 0, orc.any_hits(rays, mode) != 0)
+                r = orc.render(48, 32, mode=CPU, max_depth=2, tone=0, n_threads=8)
+                g = ex.render(48, 32, mode=CPU, max_depth=2, tone=False, algo="bvh")
+                assert g["stats"].bvh_stack_overflows > 0
+                assert np.array_equal(g["ids"], r["ids"])
+                assert ulp_diff(g["rgb"], r["linear"]).max() <= 4
+    finally:
+        if saved is None:
+            os.environ.pop("HIPEXEC_BVH_STACK_LIMIT", None)
+        else:
+            os.environ["HIPEXEC_BVH_STACK_LIMIT"] = saved
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9])
+def test_tiny_scenes(n):
+    """Root-is-a-leaf and nearly empty hierarchies."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = _nested_scene(n_levels=n - 1)
+    rng = np.random.default_rng(n)
+    o = rng.uniform([-3, -3, 10], [3, 3, 30], (500, 3))
+    tgt = rng.uniform([-5, -5, -6], [5, 5, -2], (500, 3))
+    rays = np.concatenate([o, tgt - o], 1).astype(np.float32)
+    orc = Oracle(fs)
+    with HipExecutor(fs, device=0) as ex:
+        ref = orc.closest_hits(rays, CPU); got = ex.closest_hits(rays, CPU)
+        assert np.array_equal(got["id"], ref["id"])
+        assert np.array_equal(ex.any_hits(rays, CPU) != 0, orc.any_hits(rays, CPU) != 0)
+        r = orc.render(40, 24, mode=CPU, max_depth=1, tone=0, n_threads=4)
+        g = ex.render(40, 24, mode=CPU, max_depth=1, tone=False)
+        assert np.array_equal(g["ids"], r["ids"])
