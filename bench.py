@@ -210,6 +210,10 @@ def main():
                 "avg_launch_ms": agg[f"ms{dom}"] / max(1, agg[f"l{dom}"]),
                 "kernel_ms_per_step": {f"{names[k]} ({KLABEL[k]})": agg[f"ms{k}"] / args.steps for k in range(4)},
                 "kernel_tflops": {f"{names[k]} ({KLABEL[k]})": tf(agg[f"f{k}"], agg[f"ms{k}"]) for k in range(3)}}
+        roof["lanes"] = int(st.lanes)
+        if st.lanes > 1:
+            roof["lanes_note"] = ("the frame is traced on two concurrent streams (even / odd tiles); kernel times are per-launch "
+                                  "HIP-event durations of overlapping launches and sum to more than ms_per_step")
         if algo == "bvh":
             xa = tf(agg[f"x{dom}"], agg[f"ms{dom}"])
             roof["executed"] = {"achieved": xa, "frac": xa / PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",

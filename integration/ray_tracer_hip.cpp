@@ -5,7 +5,7 @@
 // loading stay as they are.  `class OpenClExecutor` is only forward-declared for callers
 // (scene.h:19), so this file supplies its own definition: an RAII owner of a hipexec_t.
 //
-// Build inside the reference tree (see INTEGRATION.md): replace ray_tracer_cl.cpp and
+// Build inside the reference tree: replace ray_tracer_cl.cpp and
 // opencl_executor.cpp by this file in CMakeLists.txt:26-30 and link libhip_executor.so
 // instead of OpenCL.  The unit test of this repository compiles the same file against a
 // stand-in for the reference's types by defining RT_HIP_REFERENCE_HEADER.

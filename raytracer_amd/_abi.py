@@ -48,7 +48,7 @@ class Stats(C.Structure):
         ("tests_tri_closest", C.c_uint64), ("tests_sph_closest", C.c_uint64),
         ("tests_tri_any", C.c_uint64), ("tests_sph_any", C.c_uint64),
         ("tests_tri_primary", C.c_uint64), ("exact_groups", C.c_uint64 * 3), ("scanned_chunks", C.c_uint64 * 3),
-        ("bvh_nodes", C.c_uint64 * 3), ("bvh_tests", C.c_uint64 * 3), ("bvh_stack_overflows", C.c_uint64), ("algorithm", C.c_uint32),
+        ("bvh_nodes", C.c_uint64 * 3), ("bvh_tests", C.c_uint64 * 3), ("bvh_stack_overflows", C.c_uint64), ("algorithm", C.c_uint32), ("lanes", C.c_uint32),
         ("launches", C.c_uint32 * K_COUNT), ("kernel_ms", C.c_float * K_COUNT), ("total_ms", C.c_float),
     ]
 

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "hip_executor.h"
@@ -95,6 +97,13 @@ struct hipexec {
     hipexec_stats acc{};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool call_open = false;
+    // Second lane: an executor of its own (stream, work buffers, counters) on the same scene.  A frame
+    // is split into even and odd tiles that the two lanes trace concurrently, so that the thinly
+    // populated tail of one lane's kernels (a few very long rays) overlaps the other lane's work.
+    hipexec *helper = nullptr;
+    bool is_helper = false, helper_used = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::string helper_err;
 };
 
 namespace {
@@ -373,7 +382,7 @@ int timed_end(hipexec *h)
 
 inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
-int call_begin(hipexec *h, bool timing, uint32_t flags = 0)
+int call_begin(hipexec *h, bool timing, uint32_t flags)
 {
     HIPCHK(hipSetDevice(h->device));
     bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
@@ -404,6 +413,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
     h->acc.rays_shadow += h->h_cnt64[14];
     h->acc.bvh_stack_overflows = h->h_cnt64[15];
     h->acc.algorithm = h->use_bvh ? HIPEXEC_ALGO_BVH : HIPEXEC_ALGO_SCAN;
+    h->acc.lanes = (h->helper_used && h->helper) ? 2u : 1u;
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {
         float ms = 0.f;
@@ -413,6 +423,23 @@ int call_end(hipexec *h, hipexec_stats *stats)
     }
     h->timed.clear();
     h->call_open = false;
+    if (h->helper_used && h->helper && h->helper->call_open) {
+        // the second lane's share of the frame: its counters and kernel times are added to this call's
+        hipexec *g = h->helper;
+        h->helper_used = false;
+        CHK(call_end(g, nullptr));
+        const hipexec_stats &a = g->acc;
+        h->acc.rays_primary += a.rays_primary; h->acc.rays_bounce += a.rays_bounce; h->acc.rays_shadow += a.rays_shadow;
+        h->acc.tests_tri_closest += a.tests_tri_closest; h->acc.tests_sph_closest += a.tests_sph_closest;
+        h->acc.tests_tri_any += a.tests_tri_any; h->acc.tests_sph_any += a.tests_sph_any;
+        h->acc.tests_tri_primary += a.tests_tri_primary;
+        h->acc.bvh_stack_overflows += a.bvh_stack_overflows;
+        for (int k = 0; k < 3; k++) {
+            h->acc.exact_groups[k] += a.exact_groups[k]; h->acc.scanned_chunks[k] += a.scanned_chunks[k];
+            h->acc.bvh_nodes[k] += a.bvh_nodes[k]; h->acc.bvh_tests[k] += a.bvh_tests[k];
+        }
+        for (int k = 0; k < HIPEXEC_K_COUNT; k++) { h->acc.launches[k] += a.launches[k]; h->acc.kernel_ms[k] += a.kernel_ms[k]; }
+    }
     if (stats) *stats = h->acc;
     return HIPEXEC_OK;
 }
@@ -576,12 +603,14 @@ int validate_cfg(const hipexec_render_cfg *c)
     return HIPEXEC_OK;
 }
 
+// Renders the tiles sub, sub + n_sub, sub + 2 n_sub, ... of the call's tile list (n_sub = 1: all of them).
 template <int MODE>
-int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
+int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids, int sub, int n_sub)
 {
     constexpr int SPP = (MODE == HIPEXEC_MODE_CL) ? 1 : 4;
     const DScene &S = h->S;
-    int n_tiles = n_tiles_of(c);
+    int n_all = n_tiles_of(c);
+    int n_tiles = n_all > sub ? (n_all - sub + n_sub - 1) / n_sub : 0;
     int nbx = (c->width + 7) / 8;
     int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : c->max_depth;
     // tiles per batch, bounded by the shadow queue
@@ -591,8 +620,9 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
     if (h->use_bvh) tiles_per_batch = (int)std::max<uint64_t>(1, BATCH_MAX_SAMPLES / samples_per_tile);   // no shadow queue
     for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_batch) {
         Frame F;
-        F.W = c->width; F.H = c->height; F.tile_step = c->tile_step;
-        F.tile_first = c->tile_first + t0 * c->tile_step;
+        F.W = c->width; F.H = c->height; F.tile_step = c->tile_step * n_sub;
+        F.out_first = sub + t0 * n_sub; F.out_step = n_sub;
+        F.tile_first = c->tile_first + F.out_first * c->tile_step;
         F.n_tiles = std::min(tiles_per_batch, n_tiles - t0);
         F.nbx = nbx; F.n_slots = (uint32_t)F.n_tiles * (uint32_t)nbx * 64u; F.spp = SPP;
         uint64_t n0 = (uint64_t)F.n_slots * SPP;
@@ -604,12 +634,9 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         } else {
             LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>(), h->d_cnt64);
         }
-        int rows = std::min(F.n_tiles * HIPEXEC_TILE_ROWS, c->height - F.tile_first * HIPEXEC_TILE_ROWS);
-        if (c->tile_step != 1) {
-            rows = 0;
-            for (int k = 0; k < F.n_tiles; k++)
-                rows += std::max(0, std::min(HIPEXEC_TILE_ROWS, c->height - (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS));
-        }
+        int rows = 0;
+        for (int k = 0; k < F.n_tiles; k++)
+            rows += std::max(0, std::min(HIPEXEC_TILE_ROWS, c->height - (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS));
         uint64_t prim = (uint64_t)rows * c->width * SPP;
         h->acc.rays_primary += prim;
         h->acc.tests_tri_primary += prim * S.n_tri;
@@ -617,17 +644,54 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         h->acc.tests_sph_closest += prim * S.n_sph;
         int levels_used = 1;
         CHK(trace_levels<MODE>(h, (uint32_t)n0, (size_t)n0, depth, &levels_used));
-        size_t row0 = (size_t)t0 * HIPEXEC_TILE_ROWS;
         LAUNCH(HIPEXEC_K_SHADE, (k_resolve<MODE>), blocks_for(F.n_slots), F, h->local.as<float4>(), (size_t)n0, levels_used,
-               h->hit0.as<float4>(), c->tone, d_rgba + row0 * c->width, d_ids ? d_ids + row0 * c->width * SPP : nullptr);
+               h->hit0.as<float4>(), c->tone, d_rgba, d_ids);
     }
     return HIPEXEC_OK;
 }
 
+int render_sub(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids, int sub, int n_sub)
+{
+    if (c->mode == HIPEXEC_MODE_CL) return render_tiles<HIPEXEC_MODE_CL>(h, c, d_rgba, d_ids, sub, n_sub);
+    return render_tiles<HIPEXEC_MODE_CPU>(h, c, d_rgba, d_ids, sub, n_sub);
+}
+
+int call_begin(hipexec *h, bool timing, uint32_t flags);
+
 int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
 {
-    if (c->mode == HIPEXEC_MODE_CL) return render_tiles<HIPEXEC_MODE_CL>(h, c, d_rgba, d_ids);
-    return render_tiles<HIPEXEC_MODE_CPU>(h, c, d_rgba, d_ids);
+    hipexec *g = h->helper;
+    h->helper_used = false;
+    // Two lanes pay when bounce levels exist (their small, long-tailed launches overlap the other lane's
+    // large ones: C2 -8 %, C3 -6 %); a depth-0 frame is two large uniform kernels and gains nothing.
+    const bool bounces = c->mode == HIPEXEC_MODE_CPU && c->max_depth > 0;
+    if (!h->use_bvh || !g || !bounces || n_tiles_of(c) < 32) return render_sub(h, c, d_rgba, d_ids, 0, 1);
+    // fork: the helper's stream starts after everything queued on this executor's stream so far
+    h->helper_used = true;
+    g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
+    g->bvh_refill = h->bvh_refill; g->bvh_default = true;
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(g->stream, h->ev_fork, 0));
+    int rc_helper = HIPEXEC_OK;
+    std::thread worker([&]() {
+        rc_helper = [&]() -> int {
+            CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH));
+            return render_sub(g, c, d_rgba, d_ids, 1, 2);
+        }();
+        if (rc_helper != HIPEXEC_OK) h->helper_err = g_err;          // g_err is per thread
+    });
+    int rc = render_sub(h, c, d_rgba, d_ids, 0, 2);
+    worker.join();
+    // join: later work on this executor's stream waits for the helper's kernels
+    if (rc_helper == HIPEXEC_OK) {
+        HIPCHK(hipEventRecord(h->ev_join, g->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    } else {
+        (void)hipStreamSynchronize(g->stream);
+        g->call_open = false;
+        if (rc == HIPEXEC_OK) { snprintf(g_err, sizeof g_err, "%s", h->helper_err.c_str()); rc = rc_helper; }
+    }
+    return rc;
 }
 
 // rays6 (host) -> ray records in rayA, sample index = position
@@ -645,6 +709,23 @@ int import_rays(hipexec *h, const float *rays6, uint32_t n)
     CHK(h->rayA.reserve((size_t)n * 32));
     HIPCHK(hipMemcpyAsync(h->stage_in.p, rays6, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
     LAUNCH(HIPEXEC_K_SHADE, k_import_rays, blocks_for(n), h->stage_in.as<float>(), n, h->rayA.as<float4>());
+    return HIPEXEC_OK;
+}
+
+// stream, events and counters of one lane
+int create_lane_resources(hipexec *h, uint32_t n_lamp)
+{
+    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end));
+    h->n_cnt32 = std::max(8u, n_lamp + 1u);
+    HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&h->d_cnt64, N_CNT64 * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_cnt64, N_CNT64 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return HIPEXEC_OK;
 }
 
@@ -674,15 +755,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
     if (!h) return fail(HIPEXEC_E_NOMEM, "out of host memory");
     h->device = device;
     int rc = [&]() -> int {
-        HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-        h->stream = h->own_stream;
-        HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end));
-        h->n_cnt32 = std::max(8u, scene->n_lamp + 1u);
-        HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
-        HIPCHK(hipMalloc((void **)&h->d_cnt64, N_CNT64 * sizeof(unsigned long long)));
-        HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&h->h_cnt64, N_CNT64 * sizeof(unsigned long long), hipHostMallocDefault));
-        HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
+        CHK(create_lane_resources(h, scene->n_lamp));
         if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
@@ -693,11 +766,21 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
         if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
-        HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
         CHK(build_scene(h, scene));
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each
         // wave reads only the chunks it needs and the scalar path wins
         if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
+        const char *lanes = getenv("HIPEXEC_LANES");                 // "1": no second lane
+        if (h->bvh_ok && !(lanes && atoi(lanes) == 1)) {
+            hipexec *g = new (std::nothrow) hipexec();
+            if (!g) return fail(HIPEXEC_E_NOMEM, "out of host memory");
+            h->helper = g;
+            g->is_helper = true; g->device = device;
+            g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words;     // the scene stays owned by h
+            CHK(create_lane_resources(g, scene->n_lamp));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
         return HIPEXEC_OK;
     }();
     if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
@@ -709,6 +792,9 @@ void hipexec_destroy(hipexec_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->helper) { hipexec_destroy(h->helper); h->helper = nullptr; }      // owns no scene memory
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->scene_allocs) (void)hipFree(p);
     for (Buf *b : {&h->rayA, &h->rayB, &h->hit0, &h->hitN, &h->local, &h->occl, &h->shadowq, &h->out_rgba, &h->out_ids,
@@ -811,7 +897,7 @@ int hipexec_closest_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n,
     if (mode != HIPEXEC_MODE_CPU && mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", mode);
     if (n == 0) return HIPEXEC_OK;
     if (!rays6 || !out) return fail(HIPEXEC_E_INVALID, "rays6/out is NULL");
-    CHK(call_begin(h, false));
+    CHK(call_begin(h, false, 0));
     for (uint32_t off = 0; off < n; off += BATCH_API_CHUNK) {
         uint32_t m = std::min(BATCH_API_CHUNK, n - off);
         CHK(import_rays(h, rays6 + 6 * (size_t)off, m));
@@ -833,7 +919,7 @@ int hipexec_any_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, cha
     if (mode != HIPEXEC_MODE_CPU && mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", mode);
     if (n == 0) return HIPEXEC_OK;
     if (!rays6 || !hits) return fail(HIPEXEC_E_INVALID, "rays6/hits is NULL");
-    CHK(call_begin(h, false));
+    CHK(call_begin(h, false, 0));
     std::vector<uint32_t> bits;
     for (uint32_t off = 0; off < n; off += BATCH_API_CHUNK) {
         uint32_t m = std::min(BATCH_API_CHUNK, n - off);
@@ -858,7 +944,7 @@ int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6
     if (max_depth < 0 || max_depth > 64) return fail(HIPEXEC_E_LIMIT, "max_depth %d outside [0,64]", max_depth);
     if (n == 0) { if (stats) memset(stats, 0, sizeof *stats); return HIPEXEC_OK; }
     if (!rays6 || !colours3) return fail(HIPEXEC_E_INVALID, "rays6/colours3 is NULL");
-    CHK(call_begin(h, false));
+    CHK(call_begin(h, false, 0));
     const DScene &S = h->S;
     int depth = mode == HIPEXEC_MODE_CL ? 0 : max_depth;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(BATCH_API_CHUNK, SHADOW_QUEUE_MAX_ENTRIES / std::max(1u, S.n_lamp)));

@@ -24,6 +24,7 @@ namespace rt {
 struct Frame {
     int W, H;              // full frame
     int tile_first, tile_step, n_tiles;
+    int out_first, out_step;   // tile k of this call is stored as tile out_first + k * out_step of the output buffer
     int nbx;               // 8x8 blocks per tile row = ceil(W/8)
     uint32_t n_slots;      // n_tiles * nbx * 64 pixel slots (one thread each)
     int spp;
@@ -345,7 +346,7 @@ DEV bool slot_to_pixel(const Frame &F, uint32_t slot, int &x, int &y, int &lrow)
     int k = (int)(blk / (uint32_t)F.nbx), bx = (int)(blk % (uint32_t)F.nbx);
     x = bx * 8 + (int)(lane & 7);
     int ly = (int)(lane >> 3);
-    lrow = k * HIPEXEC_TILE_ROWS + ly;
+    lrow = (F.out_first + k * F.out_step) * HIPEXEC_TILE_ROWS + ly;
     y = (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS + ly;
     return slot < F.n_slots && x < F.W && y < F.H;
 }
@@ -936,23 +937,6 @@ __global__ void k_resolve_batch(uint32_t n, const float4 *__restrict__ local, si
     colours3[3 * (size_t)i] = colours3[3 * (size_t)i] + t.x;
     colours3[3 * (size_t)i + 1] = colours3[3 * (size_t)i + 1] + t.y;
     colours3[3 * (size_t)i + 2] = colours3[3 * (size_t)i + 2] + t.z;
-}
-
-// float4 RGBA tiles -> float RGB rows of the full frame (image_bitmap layout)
-__global__ void k_pack_rgb(Frame F, const float4 *__restrict__ rgba, float *__restrict__ rgb, const int32_t *__restrict__ ids_in,
-                           int32_t *__restrict__ ids_out, int spp)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t total = (uint32_t)F.n_tiles * HIPEXEC_TILE_ROWS * (uint32_t)F.W;
-    if (i >= total) return;
-    int lrow = (int)(i / (uint32_t)F.W), x = (int)(i % (uint32_t)F.W);
-    int k = lrow / HIPEXEC_TILE_ROWS, ly = lrow % HIPEXEC_TILE_ROWS;
-    int y = (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS + ly;
-    if (y >= F.H) return;
-    float4 c = rgba[i];
-    size_t p = (size_t)y * F.W + x;
-    rgb[3 * p] = c.x; rgb[3 * p + 1] = c.y; rgb[3 * p + 2] = c.z;
-    if (ids_out) for (int r = 0; r < spp; r++) ids_out[p * spp + r] = ids_in[(size_t)i * spp + r];
 }
 
 // full hit records for hipexec_closest_hits (the `Hit` of scene.h:48-63)

@@ -33,7 +33,7 @@ def _check_blocks(fs, got, W, H, depth, mode, blocks, lin=None):
 
 
 def test_c2_full_size_depth3():
-    """BASELINE config 2: 100 352 triangles, 1920x1080, 4 spp, depth-3 reflections."""
+    """Benchmark config 2: 100 352 triangles, 1920x1080, 4 spp, depth-3 reflections."""
     from raytracer_amd.executor import HipExecutor
     fs = scenegen.scene_c2().to_flat()
     W, H, depth = 1920, 1080, 3
@@ -60,7 +60,7 @@ def test_c2_full_size_depth3():
 
 
 def test_c5_many_lights_4k_strip():
-    """BASELINE config 5 (16 lamps, 16 spheres, 20k triangles) at 3840x2160: one 8-row tile in
+    """Benchmark config 5 (16 lamps, 16 spheres, 20k triangles) at 3840x2160: one 8-row tile in
     every 9 is rendered (30 tiles), oracle-checked on a grid of blocks inside those tiles."""
     from raytracer_amd.executor import HipExecutor
     fs = scenegen.scene_c5().to_flat()
@@ -78,7 +78,7 @@ def test_c5_many_lights_4k_strip():
 
 
 def test_c4_texture_heavy_cl_mode():
-    """BASELINE config 4 (8 x 2048^2 textures, 128 MB atlas) in CL-compat mode at 1920x1080."""
+    """Benchmark config 4 (8 x 2048^2 textures, 128 MB atlas) in CL-compat mode at 1920x1080."""
     from raytracer_amd.executor import HipExecutor
     fs = scenegen.scene_c4().to_flat()
     W, H = 1920, 1080
