@@ -135,3 +135,21 @@ def test_empty_inputs(backends):
         rays = _random_rays(empty, 10, 3)
         assert (e2.closest_hits(rays)["id"] == -1).all()
         assert (e2.any_hits(rays) == 0).all()
+
+
+def test_two_lane_frame(backends):
+    """Tall frames with reflections are split over two concurrent lanes (even / odd tiles); the
+    result and the counters are those of the oracle, including a ragged last tile."""
+    fs, ex, orc = backends("mirror")
+    W, H = 40, 260                                   # 33 tiles, the last one 4 rows high
+    ref = orc.render(W, H, mode=CPU, max_depth=3, tone=0, n_threads=8)
+    got = ex.render(W, H, mode=CPU, max_depth=3, tone=False, algo="bvh")
+    assert got["stats"].lanes == 2
+    assert np.array_equal(got["ids"], ref["ids"])
+    assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+    for k in ("rays_primary", "rays_bounce", "rays_shadow", "tests_tri_closest"):
+        assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
+    one = ex.render(W, H, mode=CPU, max_depth=0, tone=False, algo="bvh")       # no bounces: one lane
+    assert one["stats"].lanes == 1
+    part = ex.render(W, H, mode=CPU, max_depth=3, tone=False, algo="bvh", tile_first=1, tile_step=2, want_ids=False)
+    assert part["stats"].lanes == 1 and part["stats"].rays < got["stats"].rays      # 16 tiles: below the threshold
