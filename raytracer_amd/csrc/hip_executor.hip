@@ -703,6 +703,15 @@ __global__ void k_import_rays(const float *__restrict__ rays6, uint32_t n, float
     store_ray(recs, i, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), i, 0u);
 }
 
+// float4 RGBA pixels -> float RGB pixels (the layout of image_bitmap, image_bitmap.h:22)
+__global__ void k_strip_alpha(const float4 *__restrict__ rgba, size_t n, float *__restrict__ rgb)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 c = rgba[i];
+    rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+}
+
 int import_rays(hipexec *h, const float *rays6, uint32_t n)
 {
     CHK(h->stage_in.reserve((size_t)n * 24));
@@ -870,6 +879,17 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg, float *out_rgb, 
     CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
     int rc = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
     if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
+    if (cfg->tile_first == 0 && cfg->tile_step == 1) {
+        // whole frame: rows are already in frame order; drop the alpha lane on the device and copy
+        // straight into the caller's image (24 instead of 32 bytes per pixel over PCIe, no host pass)
+        const size_t n_px = (size_t)cfg->height * W;
+        CHK(h->stage_out.reserve(n_px * 12));
+        LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>(), n_px, h->stage_out.as<float>());
+        CHK(call_end(h, stats));
+        HIPCHK(hipMemcpy(out_rgb, h->stage_out.p, n_px * 12, hipMemcpyDeviceToHost));
+        if (out_ids) HIPCHK(hipMemcpy(out_ids, h->out_ids.p, n_px * spp * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return HIPEXEC_OK;
+    }
     CHK(call_end(h, stats));
     std::vector<float> rgba(rows * W * 4);
     HIPCHK(hipMemcpy(rgba.data(), h->out_rgba.p, rgba.size() * 4, hipMemcpyDeviceToHost));
