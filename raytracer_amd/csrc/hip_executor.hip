@@ -81,7 +81,8 @@ struct hipexec {
     int refill_closest = REFILL_BELOW;        // HIPEXEC_REFILL_CLOSEST: live lanes below which a wave fetches new rays
     bool bvh_refill = true;                   // closest-hit kernel that refills idle lanes (HIPEXEC_BVH_REFILL=0: one ray per lane)
     uint32_t lamp_words = 1;
-    std::vector<void *> scene_allocs;
+    std::vector<void *> scene_allocs;         // chunks of the scene arena
+    char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;
     Buf rayA, rayB, hit0, hitN, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
     uint32_t *d_cnt32 = nullptr;              // [0] next-level queue fill, [1 + l] shadow queue fill of lamp l
     uint32_t n_cnt32 = 0;
@@ -108,20 +109,37 @@ struct hipexec {
 
 namespace {
 
+// Scene memory comes from a few large chunks (one hipMalloc / hipFree per chunk instead of one per
+// array: creating and destroying an executor per frame, as ray_tracer_cl.cpp:14 does, stays cheap).
+int scene_alloc(hipexec *h, size_t bytes, void **out)
+{
+    constexpr size_t CHUNK = 32u << 20, ALIGN = 256;
+    bytes = (bytes + ALIGN - 1) / ALIGN * ALIGN;
+    if (h->arena_used + bytes > h->arena_cap) {
+        size_t want = std::max(bytes, CHUNK);
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, want));
+        h->scene_allocs.push_back(p);
+        h->arena = static_cast<char *>(p); h->arena_cap = want; h->arena_used = 0;
+    }
+    *out = h->arena + h->arena_used;
+    h->arena_used += bytes;
+    return HIPEXEC_OK;
+}
+
+// Device array of max(count, min_count) elements: the first `count` copied from src (if any), the
+// rest zero.  `src` must stay valid until the stream is synchronised (build_scene does that before
+// it returns).  Everything goes through the executor's stream: its set-up kernels run there and a
+// non-blocking stream is not ordered against the null stream.
 template <class T>
 int upload(hipexec *h, const T *src, size_t count, T **dst, size_t min_count = 1)
 {
     size_t n = std::max(count, min_count);
     void *p = nullptr;
-    HIPCHK(hipMalloc(&p, n * sizeof(T)));
-    h->scene_allocs.push_back(p);
-    // everything goes through the executor's stream: its set-up kernels run there and a
-    // non-blocking stream is not ordered against the null stream
-    HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), h->stream));
-    if (count && src) {
-        HIPCHK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));      // src may be a temporary of the caller
-    }
+    CHK(scene_alloc(h, n * sizeof(T), &p));
+    size_t copied = (count && src) ? count : 0;
+    if (copied) HIPCHK(hipMemcpyAsync(p, src, copied * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    if (copied < n) HIPCHK(hipMemsetAsync(static_cast<char *>(p) + copied * sizeof(T), 0, (n - copied) * sizeof(T), h->stream));
     *dst = reinterpret_cast<T *>(p);
     return HIPEXEC_OK;
 }
@@ -171,23 +189,25 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
     B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
 
-    // temporaries, released at the end
+    // temporaries: one block, carved up, released at the end
     unsigned long long *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *child = nullptr, *parent = nullptr, *range = nullptr, *arrived = nullptr;
     float4 *box_lo = nullptr, *box_hi = nullptr, *nrm_lo = nullptr, *nrm_hi = nullptr;
     void *sort_tmp = nullptr;
-    std::vector<void *> tmp;
-    auto dalloc = [&](void **p, size_t bytes) -> int {
-        HIPCHK(hipMalloc(p, std::max<size_t>(bytes, 16)));
-        tmp.push_back(*p);
-        return HIPEXEC_OK;
-    };
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+    char *block = nullptr;
+    size_t used = 0;
+    auto carve = [&](size_t bytes) -> void * { void *p = block + used; used += (bytes + 255) / 256 * 256; return p; };
+    const size_t total = 2 * (8 * (size_t)n + 256) + 3 * (8 * (size_t)n + 256) + (4 * (size_t)n + 256) + 4 * (32 * (size_t)n + 256) + tmp_bytes + 256;
+    HIPCHK(hipMalloc((void **)&block, total));
     int rc = [&]() -> int {
-        CHK(dalloc((void **)&keys_a, 8 * (size_t)n)); CHK(dalloc((void **)&keys_b, 8 * (size_t)n));
-        CHK(dalloc((void **)&child, 8 * (size_t)n)); CHK(dalloc((void **)&parent, 8 * (size_t)n));
-        CHK(dalloc((void **)&range, 8 * (size_t)n)); CHK(dalloc((void **)&arrived, 4 * (size_t)n));
-        CHK(dalloc((void **)&box_lo, 32 * (size_t)n)); CHK(dalloc((void **)&box_hi, 32 * (size_t)n));
-        CHK(dalloc((void **)&nrm_lo, 32 * (size_t)n)); CHK(dalloc((void **)&nrm_hi, 32 * (size_t)n));
+        keys_a = (unsigned long long *)carve(8 * (size_t)n); keys_b = (unsigned long long *)carve(8 * (size_t)n);
+        child = (uint32_t *)carve(8 * (size_t)n); parent = (uint32_t *)carve(8 * (size_t)n); range = (uint32_t *)carve(8 * (size_t)n);
+        arrived = (uint32_t *)carve(4 * (size_t)n);
+        box_lo = (float4 *)carve(32 * (size_t)n); box_hi = (float4 *)carve(32 * (size_t)n);
+        nrm_lo = (float4 *)carve(32 * (size_t)n); nrm_hi = (float4 *)carve(32 * (size_t)n);
+        sort_tmp = carve(tmp_bytes);
         HIPCHK(hipMemsetAsync(arrived, 0, 4 * (size_t)n, h->stream));
         f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
         float ext[3];
@@ -198,9 +218,6 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         const dim3 blk(256), grid((n + 255) / 256);
         hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
         HIPCHK(hipGetLastError());
-        size_t tmp_bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
-        CHK(dalloc(&sort_tmp, tmp_bytes));
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
         hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi, nrm_lo, nrm_hi);
         HIPCHK(hipGetLastError());
@@ -215,7 +232,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         HIPCHK(hipStreamSynchronize(h->stream));
         return HIPEXEC_OK;
     }();
-    for (void *p : tmp) (void)hipFree(p);
+    (void)hipFree(block);
     return rc;
 }
 
