@@ -213,6 +213,19 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg,
                    float *out_rgb, int32_t *out_ids, hipexec_stats *stats);
 
 /*
+ * The frame of hipexec_render delivered in steps of about `rows_per_step` rows (rounded up to
+ * whole 8-row tiles, bottom rows of the image first): after each step its rows are in out_rgb
+ * and on_rows(user, first_row, row_count) is called (may be NULL).  Counterpart of the
+ * progressive display mode, where renderParallel / taskProcessor hand finished 48x48 blocks to
+ * the display loop while the rest is still being traced (ray_tracer.cpp:57-153, main.cpp:53-90);
+ * SUB_BLOCK_HEIGHT = 48 (config.h:17) corresponds to rows_per_step = 48.  Whole frames only
+ * (tile_first 0, tile_step 1).  The pixels are identical to those of hipexec_render.
+ */
+typedef void (*hipexec_rows_cb)(void *user, int32_t first_row, int32_t row_count);
+int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int32_t rows_per_step,
+                               float *out_rgb, hipexec_rows_cb on_rows, void *user, hipexec_stats *stats);
+
+/*
  * Same work as hipexec_render but asynchronous and device-resident: results stay in device
  * memory of the executor's device, for a caller that gathers shards itself.
  *   d_out_rgba : device pointer, [n_tiles*8][width][4] floats (RGB + 1.0), the rendered

@@ -90,12 +90,16 @@ REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(REPO_ROOT, "raytracer_amd", "lib", "libhip_executor.so")
 
 # name -> (restype, argtypes); every symbol include/hip_executor.h declares
+ROWS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)
+
 PROTOTYPES = {
     "hipexec_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(SceneDesc), C.c_int]),
     "hipexec_destroy": (None, [C.c_void_p]),
     "hipexec_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hipexec_set_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
     "hipexec_render": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "hipexec_render_progressive": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(Stats)]),
     "hipexec_render_device": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "hipexec_sync": (C.c_int, [C.c_void_p]),
     "hipexec_closest_hits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <new>
 #include <string>
@@ -101,6 +102,7 @@ struct hipexec {
     // Second lane: an executor of its own (stream, work buffers, counters) on the same scene.  A frame
     // is split into even and odd tiles that the two lanes trace concurrently, so that the thinly
     // populated tail of one lane's kernels (a few very long rays) overlaps the other lane's work.
+    int win_lo = 0, win_hi = INT_MAX;         // window into the call's tile list (progressive rendering)
     hipexec *helper = nullptr;
     bool is_helper = false, helper_used = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -415,6 +417,20 @@ int call_begin(hipexec *h, bool timing, uint32_t flags)
     return HIPEXEC_OK;
 }
 
+void add_stats(hipexec_stats &d, const hipexec_stats &a)
+{
+    d.rays_primary += a.rays_primary; d.rays_bounce += a.rays_bounce; d.rays_shadow += a.rays_shadow;
+    d.tests_tri_closest += a.tests_tri_closest; d.tests_sph_closest += a.tests_sph_closest;
+    d.tests_tri_any += a.tests_tri_any; d.tests_sph_any += a.tests_sph_any;
+    d.tests_tri_primary += a.tests_tri_primary;
+    d.bvh_stack_overflows += a.bvh_stack_overflows;
+    for (int k = 0; k < 3; k++) {
+        d.exact_groups[k] += a.exact_groups[k]; d.scanned_chunks[k] += a.scanned_chunks[k];
+        d.bvh_nodes[k] += a.bvh_nodes[k]; d.bvh_tests[k] += a.bvh_tests[k];
+    }
+    for (int k = 0; k < HIPEXEC_K_COUNT; k++) { d.launches[k] += a.launches[k]; d.kernel_ms[k] += a.kernel_ms[k]; }
+}
+
 // finish a call: wait, collect timings and counters into *stats (optional)
 int call_end(hipexec *h, hipexec_stats *stats)
 {
@@ -445,17 +461,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
         hipexec *g = h->helper;
         h->helper_used = false;
         CHK(call_end(g, nullptr));
-        const hipexec_stats &a = g->acc;
-        h->acc.rays_primary += a.rays_primary; h->acc.rays_bounce += a.rays_bounce; h->acc.rays_shadow += a.rays_shadow;
-        h->acc.tests_tri_closest += a.tests_tri_closest; h->acc.tests_sph_closest += a.tests_sph_closest;
-        h->acc.tests_tri_any += a.tests_tri_any; h->acc.tests_sph_any += a.tests_sph_any;
-        h->acc.tests_tri_primary += a.tests_tri_primary;
-        h->acc.bvh_stack_overflows += a.bvh_stack_overflows;
-        for (int k = 0; k < 3; k++) {
-            h->acc.exact_groups[k] += a.exact_groups[k]; h->acc.scanned_chunks[k] += a.scanned_chunks[k];
-            h->acc.bvh_nodes[k] += a.bvh_nodes[k]; h->acc.bvh_tests[k] += a.bvh_tests[k];
-        }
-        for (int k = 0; k < HIPEXEC_K_COUNT; k++) { h->acc.launches[k] += a.launches[k]; h->acc.kernel_ms[k] += a.kernel_ms[k]; }
+        add_stats(h->acc, g->acc);
     }
     if (stats) *stats = h->acc;
     return HIPEXEC_OK;
@@ -626,8 +632,9 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
 {
     constexpr int SPP = (MODE == HIPEXEC_MODE_CL) ? 1 : 4;
     const DScene &S = h->S;
-    int n_all = n_tiles_of(c);
-    int n_tiles = n_all > sub ? (n_all - sub + n_sub - 1) / n_sub : 0;
+    int n_all = std::min(n_tiles_of(c), h->win_hi);
+    const int first = h->win_lo + sub;
+    int n_tiles = n_all > first ? (n_all - first + n_sub - 1) / n_sub : 0;
     int nbx = (c->width + 7) / 8;
     int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : c->max_depth;
     // tiles per batch, bounded by the shadow queue
@@ -638,7 +645,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
     for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_batch) {
         Frame F;
         F.W = c->width; F.H = c->height; F.tile_step = c->tile_step * n_sub;
-        F.out_first = sub + t0 * n_sub; F.out_step = n_sub;
+        F.out_first = first + t0 * n_sub; F.out_step = n_sub;
         F.tile_first = c->tile_first + F.out_first * c->tile_step;
         F.n_tiles = std::min(tiles_per_batch, n_tiles - t0);
         F.nbx = nbx; F.n_slots = (uint32_t)F.n_tiles * (uint32_t)nbx * 64u; F.spp = SPP;
@@ -682,7 +689,9 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     // Two lanes pay when bounce levels exist (their small, long-tailed launches overlap the other lane's
     // large ones: C2 -8 %, C3 -6 %); a depth-0 frame is two large uniform kernels and gains nothing.
     const bool bounces = c->mode == HIPEXEC_MODE_CPU && c->max_depth > 0;
-    if (!h->use_bvh || !g || !bounces || n_tiles_of(c) < 32) return render_sub(h, c, d_rgba, d_ids, 0, 1);
+    const int n_window = std::min(n_tiles_of(c), h->win_hi) - h->win_lo;
+    if (!h->use_bvh || !g || !bounces || n_window < 32) return render_sub(h, c, d_rgba, d_ids, 0, 1);
+    g->win_lo = h->win_lo; g->win_hi = h->win_hi;
     // fork: the helper's stream starts after everything queued on this executor's stream so far
     h->helper_used = true;
     g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
@@ -926,6 +935,45 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg, float *out_rgb, 
         }
     }
     return HIPEXEC_OK;
+}
+
+int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int32_t rows_per_step, float *out_rgb,
+                               hipexec_rows_cb on_rows, void *user, hipexec_stats *stats)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    CHK(validate_cfg(cfg));
+    if (!out_rgb) return fail(HIPEXEC_E_INVALID, "out_rgb is NULL");
+    if (cfg->tile_first != 0 || cfg->tile_step != 1) return fail(HIPEXEC_E_INVALID, "progressive rendering takes whole frames (tile_first 0, tile_step 1)");
+    if (rows_per_step < 1) return fail(HIPEXEC_E_INVALID, "rows_per_step %d is not positive", rows_per_step);
+    const int n_tiles = n_tiles_of(cfg);
+    const int tiles_per_step = std::max(1, (rows_per_step + HIPEXEC_TILE_ROWS - 1) / HIPEXEC_TILE_ROWS);
+    const size_t W = (size_t)cfg->width;
+    HIPCHK(hipSetDevice(h->device));
+    CHK(h->out_rgba.reserve((size_t)n_tiles * HIPEXEC_TILE_ROWS * W * 16));
+    CHK(h->stage_out.reserve((size_t)tiles_per_step * HIPEXEC_TILE_ROWS * W * 12));
+    hipexec_stats total{};
+    int rc = HIPEXEC_OK;
+    for (int t0 = 0; t0 < n_tiles && rc == HIPEXEC_OK; t0 += tiles_per_step) {
+        rc = [&]() -> int {
+            h->win_lo = t0; h->win_hi = std::min(n_tiles, t0 + tiles_per_step);
+            CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
+            int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), nullptr);
+            if (r != HIPEXEC_OK) { h->call_open = false; return r; }
+            const int y0 = t0 * HIPEXEC_TILE_ROWS, rows = std::min(cfg->height, h->win_hi * HIPEXEC_TILE_ROWS) - y0;
+            const size_t n_px = (size_t)rows * W;
+            LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>() + (size_t)y0 * W, n_px, h->stage_out.as<float>());
+            hipexec_stats st{};
+            CHK(call_end(h, &st));
+            HIPCHK(hipMemcpy(out_rgb + (size_t)y0 * W * 3, h->stage_out.p, n_px * 12, hipMemcpyDeviceToHost));
+            add_stats(total, st);
+            total.total_ms += st.total_ms; total.algorithm = st.algorithm; total.lanes = std::max(total.lanes, st.lanes);
+            if (on_rows) on_rows(user, y0, rows);
+            return HIPEXEC_OK;
+        }();
+    }
+    h->win_lo = 0; h->win_hi = INT_MAX;
+    if (rc == HIPEXEC_OK && stats) *stats = total;
+    return rc;
 }
 
 int hipexec_closest_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, hipexec_hit *out)

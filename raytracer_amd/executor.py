@@ -93,6 +93,19 @@ class HipExecutor:
                                              ids.ctypes.data if ids is not None else None, C.byref(st)))
         return {"rgb": rgb, "ids": ids, "stats": st}
 
+    def render_progressive(self, width, height, rows_per_step=48, on_rows=None, mode=HIPEXEC_MODE_CPU, max_depth=0,
+                           tone=True, out=None, algo=None):
+        """Render to host memory in steps of `rows_per_step` rows; `on_rows(first_row, row_count)` is called
+        after each step with those rows already in the image.  -> dict(rgb, stats)."""
+        rgb = out if out is not None else np.zeros((height, width, 3), np.float32)
+        assert rgb.dtype == np.float32 and rgb.flags.c_contiguous and rgb.shape == (height, width, 3)
+        st = _abi.Stats()
+        cfg = self._cfg(width, height, mode, max_depth, tone, 0, 1, False, algo)
+        cb = _abi.ROWS_CB((lambda user, y0, rows: on_rows(int(y0), int(rows))) if on_rows else (lambda user, y0, rows: None))
+        self._check(self._lib.hipexec_render_progressive(self._h, C.byref(cfg), int(rows_per_step), rgb.ctypes.data,
+                                                         C.cast(cb, C.c_void_p), None, C.byref(st)))
+        return {"rgb": rgb, "stats": st}
+
     def render_device(self, width, height, d_out_rgba: int, d_out_ids: int | None = None, mode=HIPEXEC_MODE_CPU,
                       max_depth=0, tone=True, tile_first=0, tile_step=1, time_kernels=False, stats=None, algo=None):
         """Render into device memory (raw device pointers, e.g. torch.Tensor.data_ptr()).

@@ -153,3 +153,25 @@ def test_two_lane_frame(backends):
     assert one["stats"].lanes == 1
     part = ex.render(W, H, mode=CPU, max_depth=3, tone=False, algo="bvh", tile_first=1, tile_step=2, want_ids=False)
     assert part["stats"].lanes == 1 and part["stats"].rays < got["stats"].rays      # 16 tiles: below the threshold
+
+
+@pytest.mark.parametrize("mode,depth", [(CPU, 2), (CL, 0)])
+def test_progressive_render_delivers_the_same_frame_in_steps(backends, mode, depth):
+    fs, ex, orc = backends("c2")
+    W, H = 56, 100                                   # 13 tiles, the last one 4 rows high
+    full = ex.render(W, H, mode=mode, max_depth=depth, tone=True, want_ids=False)
+    img = np.full((H, W, 3), -7.0, np.float32)
+    seen = []
+
+    def on_rows(y0, rows):
+        # the rows of this step are final, later rows are still untouched
+        assert np.array_equal(img[y0:y0 + rows].view(np.int32), full["rgb"][y0:y0 + rows].view(np.int32))
+        assert (img[y0 + rows:] == -7.0).all()
+        seen.append((y0, rows))
+
+    got = ex.render_progressive(W, H, rows_per_step=20, on_rows=on_rows, mode=mode, max_depth=depth, out=img)
+    assert seen == [(0, 24), (24, 24), (48, 24), (72, 24), (96, 4)]
+    assert np.array_equal(img.view(np.int32), full["rgb"].view(np.int32))
+    assert got["stats"].rays == full["stats"].rays
+    with pytest.raises(RuntimeError):
+        ex._check(ex._lib.hipexec_render_progressive(ex._h, None, 8, img.ctypes.data, None, None, None))
