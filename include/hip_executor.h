@@ -112,6 +112,10 @@ typedef struct hipexec_render_cfg {
 #define HIPEXEC_FLAG_BVH          4   /* this call: bounding volume hierarchy (the default unless
                                          the environment says HIPEXEC_ALGO=scan)                 */
 
+#define HIPEXEC_FLAG_BILINEAR      8   /* NOT a reference mode: textured hits blend the four texels around
+                                         (u - 0.5, v - 0.5) instead of taking tex_image::get's single texel
+                                         (tex_image.h:34-44).  Frame entry points only.                     */
+
 /* Both algorithms evaluate the same exact ray/primitive arithmetic and return identical hits and
  * colours; they differ in which tests they can prove unnecessary. */
 enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };

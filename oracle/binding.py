@@ -29,6 +29,8 @@ def lib():
         L.orc_triangle_hit.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp, fp]
         L.orc_sphere_hit.restype = C.c_int
         L.orc_sphere_hit.argtypes = [C.c_int, fp, C.c_float, fp, fp, fp, fp, fp]
+        L.orc_tex_bilinear.restype = None
+        L.orc_tex_bilinear.argtypes = [C.POINTER(_abi.SceneDesc), C.c_int, C.c_float, C.c_float, fp]
         L.orc_tex_get.restype = None
         L.orc_tex_get.argtypes = [C.POINTER(_abi.SceneDesc), C.c_int, C.c_uint, C.c_uint, fp]
         L.orc_closest_hits.restype = None
@@ -83,6 +85,11 @@ class Oracle:
                           out.ctypes.data_as(C.POINTER(C.c_float)))
         return out
 
+    def tex_bilinear(self, tex, ux, uy):
+        out = np.zeros(4, np.float32)
+        lib().orc_tex_bilinear(C.byref(self.desc), int(tex), C.c_float(ux), C.c_float(uy), out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
     def closest_hits(self, rays6, mode=_abi.HIPEXEC_MODE_CPU):
         rays = np.ascontiguousarray(rays6, dtype=np.float32).reshape(-1, 6)
         out = np.zeros(rays.shape[0], dtype=_abi.HIT_DTYPE)
@@ -105,9 +112,10 @@ class Oracle:
                              C.byref(stats) if stats is not None else None)
         return colours
 
-    def render_region(self, width, height, x, y, w, h, mode=_abi.HIPEXEC_MODE_CPU, max_depth=0, tone=1, n_threads=1):
+    def render_region(self, width, height, x, y, w, h, mode=_abi.HIPEXEC_MODE_CPU, max_depth=0, tone=1, n_threads=1,
+                      bilinear=False):
         """-> dict(rgb [h][w][3], linear [h][w][3], ids [h][w][spp], stats)"""
-        cfg = _abi.RenderCfg(width, height, mode, max_depth, tone, 0, 1, 0)
+        cfg = _abi.RenderCfg(width, height, mode, max_depth, tone, 0, 1, _abi.HIPEXEC_FLAG_BILINEAR if bilinear else 0)
         spp = 1 if mode == _abi.HIPEXEC_MODE_CL else 4
         rgb = np.zeros((h, w, 3), np.float32); lin = np.zeros((h, w, 3), np.float32)
         ids = np.full((h, w, spp), -2, np.int32)

@@ -186,6 +186,30 @@ void orc_tex_get(const hipexec_scene_desc *s, int tex, unsigned x, unsigned y, f
     rgba[3] = (float)img[index + 3] / 255.0f;
 }
 
+static unsigned f2u_x86(float f);
+
+/* Optional, not in the reference: the four texels around (ux - 0.5, uy - 0.5), each fetched with
+ * orc_tex_get (same wrap and flip), blended in x then in y.  Texel i is centred at i + 0.5, so
+ * at texel centres this equals the reference's lookup. */
+void orc_tex_bilinear(const hipexec_scene_desc *s, int tex, float ux, float uy, float rgba[4])
+{
+    float fx = ux - 0.5f, fy = uy - 0.5f;
+    float x0 = floorf(fx), y0 = floorf(fy);
+    float ax = fx - x0, ay = fy - y0;
+    float c00[4], c10[4], c01[4], c11[4];
+    orc_tex_get(s, tex, f2u_x86(x0), f2u_x86(y0), c00);
+    orc_tex_get(s, tex, f2u_x86(x0 + 1.0f), f2u_x86(y0), c10);
+    orc_tex_get(s, tex, f2u_x86(x0), f2u_x86(y0 + 1.0f), c01);
+    orc_tex_get(s, tex, f2u_x86(x0 + 1.0f), f2u_x86(y0 + 1.0f), c11);
+    for (int k = 0; k < 4; k++) {
+        float top = c00[k] * (1.0f - ax) + c10[k] * ax;
+        float bot = c01[k] * (1.0f - ax) + c11[k] * ax;
+        rgba[k] = top * (1.0f - ay) + bot * ay;
+    }
+}
+
+static __thread int tl_bilinear = 0;      /* set per worker thread from hipexec_render_cfg.flags */
+
 /* (unsigned int) of a float as x86-64 gcc evaluates it: truncate to a 64-bit integer, keep
  * the low 32 bits (ray_tracer.cpp:236-237).  Out-of-range and NaN give 0 like cvttss2si. */
 static unsigned f2u_x86(float f)
@@ -222,7 +246,8 @@ static v3 tri_color(const hipexec_scene_desc *s, uint32_t i, const mat_t *m, flo
         float ux = uv[0] + uv[2] * u + uv[4] * v;
         float uy = uv[1] + uv[3] * u + uv[5] * v;
         float rgba[4];
-        orc_tex_get(s, m->tex, f2u_x86(ux), f2u_x86(uy), rgba);
+        if (tl_bilinear) orc_tex_bilinear(s, m->tex, ux, uy, rgba);
+        else orc_tex_get(s, m->tex, f2u_x86(ux), f2u_x86(uy), rgba);
         v3 texc = smul(rgba[3], V(rgba[0], rgba[1], rgba[2]));
         return add(texc, smul(1 - rgba[3], m->color));
     }
@@ -424,6 +449,7 @@ static void render_block(const job_t *J, int bx, int by, int bw, int bh, hipexec
     const hipexec_scene_desc *s = J->s;
     int width = J->cfg->width, height = J->cfg->height;
     int cl = (J->cfg->mode == HIPEXEC_MODE_CL);
+    tl_bilinear = (J->cfg->flags & HIPEXEC_FLAG_BILINEAR) != 0;
     int spp = cl ? 1 : 4;
     float camHeight = 0.5;
     float camWidth = (float)width * (camHeight / (float)height);

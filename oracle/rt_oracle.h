@@ -36,6 +36,8 @@ int orc_sphere_hit(int mode, const float c[3], float r, const float o[3], const 
 
 /* tex_image::get (tex_image.h:34-44) on texture `tex` of the scene; rgba receives 4 floats. */
 void orc_tex_get(const hipexec_scene_desc *s, int tex, unsigned x, unsigned y, float rgba[4]);
+/* optional non-reference mode HIPEXEC_FLAG_BILINEAR (texel units, texel i centred at i + 0.5) */
+void orc_tex_bilinear(const hipexec_scene_desc *s, int tex, float ux, float uy, float rgba[4]);
 
 /* computeClosestHit (ray_tracer.cpp:204-273) / computeClosestHitsCl (ray_tracer_cl.cpp:181-242
  * with the host reductions of opencl_executor.cpp:217-259, 406-444). */

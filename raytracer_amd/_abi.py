@@ -12,6 +12,7 @@ HIPEXEC_TILE_ROWS = 8
 HIPEXEC_FLAG_TIME_KERNELS = 1
 HIPEXEC_FLAG_SCAN = 2
 HIPEXEC_FLAG_BVH = 4
+HIPEXEC_FLAG_BILINEAR = 8
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
 ABI_VERSION = 2

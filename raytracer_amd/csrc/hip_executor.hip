@@ -406,6 +406,7 @@ int call_begin(hipexec *h, bool timing, uint32_t flags)
     HIPCHK(hipSetDevice(h->device));
     bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
     h->use_bvh = want_bvh && h->bvh_ok;
+    h->S.bilinear = (flags & HIPEXEC_FLAG_BILINEAR) ? 1u : 0u;
     if (h->call_open) {   // a previous asynchronous call has not been collected yet
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -701,7 +702,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     int rc_helper = HIPEXEC_OK;
     std::thread worker([&]() {
         rc_helper = [&]() -> int {
-            CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH));
+            CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & HIPEXEC_FLAG_BILINEAR)));
             return render_sub(g, c, d_rgba, d_ids, 1, 2);
         }();
         if (rc_helper != HIPEXEC_OK) h->helper_err = g_err;          // g_err is per thread

@@ -82,6 +82,7 @@ struct DScene {
     // {centre, A} {half extent, e_abs} {A * |half extent|_1, 0, 0, 0} (see chunk_may_hit)
     const float4 *chunk_box;
     uint32_t cull;           // 1: skip chunks no ray of the wave can hit; 0: scan every chunk
+    uint32_t bilinear;       // 1: HIPEXEC_FLAG_BILINEAR for this call (not a reference mode)
     const float *tri_norm;   // [n][3]
     const float *tri_uv;     // [n][6]
     const int *tri_mat;      // [n]  (index n_mat = default material)
@@ -308,6 +309,25 @@ DEV float4 tex_get(const DScene &S, int tex, uint32_t x, uint32_t y) {
     return make_float4((float)px.x / 255.0f, (float)px.y / 255.0f, (float)px.z / 255.0f, (float)px.w / 255.0f);
 }
 
+// HIPEXEC_FLAG_BILINEAR (not in the reference): the four texels around (ux - 0.5, uy - 0.5), each
+// fetched with tex_get (same wrap and flip), blended in x then in y; texel i is centred at i + 0.5.
+DEV float4 tex_bilinear(const DScene &S, int tex, float ux, float uy) {
+    float fx = ux - 0.5f, fy = uy - 0.5f;
+    float x0 = floorf(fx), y0 = floorf(fy);
+    float ax = fx - x0, ay = fy - y0;
+    float4 c00 = tex_get(S, tex, f2u_x86(x0), f2u_x86(y0)), c10 = tex_get(S, tex, f2u_x86(x0 + 1.0f), f2u_x86(y0));
+    float4 c01 = tex_get(S, tex, f2u_x86(x0), f2u_x86(y0 + 1.0f)), c11 = tex_get(S, tex, f2u_x86(x0 + 1.0f), f2u_x86(y0 + 1.0f));
+    float a[4] = {c00.x, c00.y, c00.z, c00.w}, b[4] = {c10.x, c10.y, c10.z, c10.w};
+    float c[4] = {c01.x, c01.y, c01.z, c01.w}, e[4] = {c11.x, c11.y, c11.z, c11.w}, r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float top = a[k] * (1.0f - ax) + b[k] * ax;
+        float bot = c[k] * (1.0f - ax) + e[k] * ax;
+        r[k] = top * (1.0f - ay) + bot * ay;
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // ray_tracer.cpp:232-268 / ray_tracer_cl.cpp:213-240.  `want_color` = false skips the
 // material/texture part (shadow-ray generation only needs P and N).
 DEV Surf surface(const DScene &S, f3 o, f3 d, float4 h, bool want_color) {
@@ -333,7 +353,7 @@ DEV Surf surface(const DScene &S, f3 o, f3 d, float4 h, bool want_color) {
         const float *uv = S.tri_uv + 6 * (size_t)id;
         float ux = uv[0] + uv[2] * h.y + uv[4] * h.z;
         float uy = uv[1] + uv[3] * h.y + uv[5] * h.z;
-        float4 c = tex_get(S, tex, f2u_x86(ux), f2u_x86(uy));
+        float4 c = S.bilinear ? tex_bilinear(S, tex, ux, uy) : tex_get(S, tex, f2u_x86(ux), f2u_x86(uy));
         r.color = c.w * mk(c.x, c.y, c.z) + (1 - c.w) * xyz(ma);
     }
     return r;

@@ -175,3 +175,20 @@ def test_progressive_render_delivers_the_same_frame_in_steps(backends, mode, dep
     assert got["stats"].rays == full["stats"].rays
     with pytest.raises(RuntimeError):
         ex._check(ex._lib.hipexec_render_progressive(ex._h, None, 8, img.ctypes.data, None, None, None))
+
+
+@pytest.mark.parametrize("name", ["c2", "c4", "ties"])
+def test_bilinear_mode_matches_its_cpu_definition(backends, name):
+    """The optional bilinear texture mode (no reference counterpart) against the oracle's definition."""
+    fs, ex, orc = backends(name)
+    W, H = 64, 48
+    for mode, depth in ((CPU, 2), (CL, 0)):
+        ref = orc.render(W, H, mode=mode, max_depth=depth, tone=0, n_threads=8, bilinear=True)
+        near = orc.render(W, H, mode=mode, max_depth=depth, tone=0, n_threads=8)
+        for algo in ("bvh", "scan"):
+            got = ex.render(W, H, mode=mode, max_depth=depth, tone=False, bilinear=True, algo=algo)
+            assert np.array_equal(got["ids"], ref["ids"])
+            assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+        assert not np.array_equal(ref["linear"], near["linear"])          # the mode does something
+        back = ex.render(W, H, mode=mode, max_depth=depth, tone=False)     # and is off again afterwards
+        assert ulp_diff(back["rgb"], near["linear"]).max() <= 4

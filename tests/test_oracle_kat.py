@@ -256,3 +256,25 @@ def test_render_region_matches_full_frame_and_threads():
     lin = full["linear"]
     tone = np.power((lin / f32(2.2)).astype(np.float64), 0.3).astype(f32)
     assert np.max(np.abs(tone - full["rgb"])) <= 2e-7
+
+
+def test_bilinear_mode_is_the_nearest_lookup_at_texel_centres_and_blends_between():
+    """HIPEXEC_FLAG_BILINEAR is not a reference mode; its definition: texel i is centred at i + 0.5,
+    the four neighbours come from tex_image::get (same wrap, same vertical flip)."""
+    from raytracer_amd.scene import FlatScene
+    fs = FlatScene()
+    tex = np.zeros((4, 4, 4), np.uint8)
+    tex[..., 0] = np.arange(16).reshape(4, 4) * 16          # red ramp
+    tex[..., 3] = 255
+    fs.textures = [tex]
+    o = orc.Oracle(fs.normalised())
+    for x in range(4):
+        for y in range(4):
+            assert np.array_equal(o.tex_bilinear(0, x + 0.5, y + 0.5), o.tex_get(0, x, y))
+    a, b = o.tex_get(0, 1, 2), o.tex_get(0, 2, 2)
+    mid = o.tex_bilinear(0, 2.0, 2.5)                       # half way between texel 1 and texel 2 of row 2
+    assert np.allclose(mid, 0.5 * (a + b), rtol=0, atol=1e-7)
+    q = o.tex_bilinear(0, 1.75, 2.25)
+    c = [o.tex_get(0, 1, 1), o.tex_get(0, 2, 1), o.tex_get(0, 1, 2), o.tex_get(0, 2, 2)]
+    want = (c[0] * 0.75 + c[1] * 0.25) * 0.25 + (c[2] * 0.75 + c[3] * 0.25) * 0.75
+    assert np.allclose(q, want, rtol=0, atol=1e-6)
