@@ -186,7 +186,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 1));
     CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
-    CHK(upload<float4>(h, nullptr, 0, &nodes, 6 * (size_t)n + 1));
+    CHK(upload<float4>(h, nullptr, 0, &nodes, 9 * (size_t)n + 1));
     B.tris = tris; B.ids = ids; B.nodes = nodes;
     if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
     B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
@@ -691,7 +691,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     // large ones: C2 -8 %, C3 -6 %); a depth-0 frame is two large uniform kernels and gains nothing.
     const bool bounces = c->mode == HIPEXEC_MODE_CPU && c->max_depth > 0;
     const int n_window = std::min(n_tiles_of(c), h->win_hi) - h->win_lo;
-    if (!h->use_bvh || !g || !bounces || n_window < 32) return render_sub(h, c, d_rgba, d_ids, 0, 1);
+    if (!h->use_bvh || !g || !bounces || n_window < 8) return render_sub(h, c, d_rgba, d_ids, 0, 1);
     g->win_lo = h->win_lo; g->win_hi = h->win_hi;
     // fork: the helper's stream starts after everything queued on this executor's stream so far
     h->helper_used = true;

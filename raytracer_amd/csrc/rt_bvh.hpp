@@ -15,8 +15,9 @@
 //   k_bvh_split   binary radix tree over the sorted keys, one thread per internal node
 //                 (longest-common-prefix construction; every node knows its key range)
 //   k_bvh_refit   boxes bottom-up, second thread to arrive at a node computes it
-//   k_bvh_emit    traversal nodes: both child boxes and normal cones in one 96-byte record;
-//                 subtrees with at most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
+//   k_bvh_emit    4-wide traversal nodes: the boxes of a node's grandchildren and the node's normal
+//                 cone in one 144-byte record, so a ray makes half the dependent fetches of a binary
+//                 walk; subtrees with at most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
 // Frame kernels: k_raygen, k_bvh_closest_p (lanes take the next ray of their block when theirs is
 // decided), k_bvh_shadow (shadow rays compacted per block in LDS); k_bvh_closest and k_bvh_anyhit
 // are the plain one-ray-per-lane forms used by the batch entry points and for A/B runs.
@@ -28,14 +29,15 @@ namespace rt {
 constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 2;
-constexpr int BVH_STACK = 24;                   // LDS stack entries per lane
+constexpr int BVH_STACK = 32;                   // LDS stack entries per lane (a node pushes up to three)
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
 constexpr float BVH_TIGHT = 4.0e-6f;
 constexpr float BVH_TIGHT_MIN = 500.0f;         // tight bound used only if (|cos| * sine) >= BVH_TIGHT * BVH_TIGHT_MIN = 2e-3
 
 struct DBvh {
-    const float4 *nodes;    // 6 float4 per internal node, 3 per child: {lo, A} {hi, ref} {cone axis * k, cone sine * k}
+    const float4 *nodes;    // 9 float4 per internal node: 4 x {lo, A}, 4 x {hi, ref} of up to four grandchildren (unused
+                            // slots have ref BVH_NONE), then the cone {axis * k, sine * k} of the node's own triangles
     const float4 *tris;     // 3 float4 per triangle in key order: {p, c21.x} {e1, c21.y} {e2, c21.z}
     const uint32_t *ids;    // triangle index of the k-th record
     uint32_t root;          // reference of the root (BVH_NONE for an empty scene)
@@ -187,19 +189,28 @@ DEV float4 bvh_cone(float4 nl, float4 nh) {
     return make_float4(a.x * (ca * k), a.y * (ca * k), a.z * (ca * k), sa * k);
 }
 
+// A node lists its grandchildren (a child that is a leaf stays one slot) and carries one cone, that
+// of all its triangles.  (A cone per slot prunes a little more but the larger record costs more
+// than that saves.)
 __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ range,
-                           const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
-                           const float4 *__restrict__ nrm_lo, const float4 *__restrict__ nrm_hi, float4 *__restrict__ nodes)
+                            const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
+                            const float4 *__restrict__ nrm_lo, const float4 *__restrict__ nrm_hi, float4 *__restrict__ nodes)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < 2 || i >= n - 1) return;
-    uint32_t a = child[2 * i], b = child[2 * i + 1];
-    float4 la = box_lo[a], ha = box_hi[a], lb = box_lo[b], hb = box_hi[b];
-    ha.w = __uint_as_float(bvh_ref_of(a, n, range));
-    hb.w = __uint_as_float(bvh_ref_of(b, n, range));
-    float4 *N = nodes + 6 * (size_t)i;
-    N[0] = la; N[1] = ha; N[2] = bvh_cone(nrm_lo[a], nrm_hi[a]);
-    N[3] = lb; N[4] = hb; N[5] = bvh_cone(nrm_lo[b], nrm_hi[b]);
+    uint32_t slot[4]; int ns = 0;
+    for (int side = 0; side < 2; side++) {
+        uint32_t c = child[2 * i + side];
+        if (bvh_ref_of(c, n, range) & BVH_LEAF) slot[ns++] = c;
+        else { slot[ns++] = child[2 * c]; slot[ns++] = child[2 * c + 1]; }
+    }
+    float4 *N = nodes + 9 * (size_t)i;
+    for (int k = 0; k < 4; k++) {
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = make_float4(0.f, 0.f, 0.f, __uint_as_float(BVH_NONE));   // unused slot
+        if (k < ns) { lo = box_lo[slot[k]]; hi = box_hi[slot[k]]; hi.w = __uint_as_float(bvh_ref_of(slot[k], n, range)); }
+        N[k] = lo; N[4 + k] = hi;
+    }
+    N[8] = bvh_cone(nrm_lo[i], nrm_hi[i]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -240,15 +251,14 @@ DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     return r;
 }
 
-// entry parameter of the enlarged box if the half-line t >= 0 may reach it at t <= limit
-DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float4 cone, float limit, float &tnear) {
+// entry parameter of the enlarged box if the half-line t >= 0 may reach it at t <= limit;
+// `rg` = 1/g for the cone the box belongs to, or 0 where the tight form does not apply
+DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float rg, float limit, float &tnear) {
     float lx = lo.x - r.o.x, ly = lo.y - r.o.y, lz = lo.z - r.o.z;
     float hx = hi.x - r.o.x, hy = hi.y - r.o.y, hz = hi.z - r.o.z;
     float qb = (fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy))) + fmaxf(fabsf(lz), fabsf(hz));
     float in = (lo.w * r.dlen) * qb;
-    float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
-    float tight = qb * __builtin_amdgcn_rcpf(g);
-    if (g >= BVH_TIGHT_MIN) in = fminf(in, tight);
+    if (rg > 0.0f) in = fminf(in, qb * rg);
     in += r.E;
     float t1x = (lx - in) * r.inv.x, t2x = (hx + in) * r.inv.x;
     float t1y = (ly - in) * r.inv.y, t2y = (hy + in) * r.inv.y;
@@ -316,7 +326,7 @@ struct TState { uint32_t node; int sp; float limit; uint32_t found, overflow; };
 DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris, uint32_t n_rays);
 
 // Every iteration the wave takes ONE of two steps, whichever more of its lanes are waiting for:
-// the inner-node step (two box tests, push/pop) or the leaf step (exact tests).  Lanes waiting for
+// the inner-node step (four box tests, push/pop) or the leaf step (exact tests).  Lanes waiting for
 // the other kind sit the iteration out.  (`sched` = 0 selects the classic while-while order instead:
 // inner nodes until no lane has one, then leaves.)
 template <int MODE, bool ANY>
@@ -336,20 +346,34 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
         const bool inner_step = sched ? (n_inner * 8 >= n_leaf * sched) : (n_inner > 0);
         if (inner_step) {
             if (at_inner) {
-                const float4 *N = B.nodes + 6 * (size_t)node;
-                float4 l0 = N[0], h0 = N[1], c0 = N[2], l1 = N[3], h1 = N[4], c1 = N[5];
                 n_nodes++;
-                float t0, t1;
-                bool hit0 = bvh_box(r, l0, h0, c0, limit, t0), hit1 = bvh_box(r, l1, h1, c1, limit, t1);
-                uint32_t r0 = __float_as_uint(h0.w), r1 = __float_as_uint(h1.w);
-                if (hit0 && hit1) {
-                    bool swap = t1 < t0;
-                    uint32_t far = swap ? r0 : r1;
-                    node = swap ? r1 : r0;
-                    if (sp < B.stack_limit) { stk[256 * sp] = far; sp++; }
-                    else { overflow = 1u; node = BVH_NONE; }
-                } else if (hit0) node = r0;
-                else if (hit1) node = r1;
+                const float4 *N = B.nodes + 9 * (size_t)node;
+                float4 lo[4], hi[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { lo[k] = N[k]; hi[k] = N[4 + k]; }
+                float4 cone = N[8];
+                float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
+                float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
+                float tk[4]; bool hk[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
+                // hit slots in order of entry: the nearest is visited next, the others go on the stack, farthest first
+                float key[4]; uint32_t ref[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { key[k] = hk[k] ? fminf(tk[k], 3.0e38f) : __builtin_inff(); ref[k] = hk[k] ? __float_as_uint(hi[k].w) : BVH_NONE; }
+#define BVH_CSWAP(a, b) { bool sw = key[b] < key[a]; float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
+                          uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; }
+                BVH_CSWAP(0, 1) BVH_CSWAP(2, 3) BVH_CSWAP(0, 2) BVH_CSWAP(1, 3) BVH_CSWAP(1, 2)
+#undef BVH_CSWAP
+#pragma unroll
+                for (int k = 3; k >= 1; k--) {
+                    if (ref[k] != BVH_NONE) {
+                        if (sp < B.stack_limit) { stk[256 * sp] = ref[k]; sp++; }
+                        else overflow = 1u;
+                    }
+                }
+                if (overflow) node = BVH_NONE;
+                else if (ref[0] != BVH_NONE) node = ref[0];
                 else if (sp > 0) { sp--; node = stk[256 * sp]; }
                 else node = BVH_NONE;
             }

@@ -151,8 +151,17 @@ def test_two_lane_frame(backends):
         assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
     one = ex.render(W, H, mode=CPU, max_depth=0, tone=False, algo="bvh")       # no bounces: one lane
     assert one["stats"].lanes == 1
-    part = ex.render(W, H, mode=CPU, max_depth=3, tone=False, algo="bvh", tile_first=1, tile_step=2, want_ids=False)
-    assert part["stats"].lanes == 1 and part["stats"].rays < got["stats"].rays      # 16 tiles: below the threshold
+    # shards: 16 tiles still run on two lanes, 4 tiles are below the threshold; either way the shard's rows are the frame's
+    for first, step, lanes in ((1, 2, 2), (3, 8, 1)):
+        img = np.full((H, W, 3), -7.0, np.float32)
+        part = ex.render(W, H, mode=CPU, max_depth=3, tone=False, algo="bvh", tile_first=first, tile_step=step, want_ids=False, out=img)
+        assert part["stats"].lanes == lanes and part["stats"].rays < got["stats"].rays
+        for t in range((H + 7) // 8):
+            rows = slice(8 * t, min(8 * t + 8, H))
+            if t >= first and (t - first) % step == 0:
+                assert np.array_equal(img[rows].view(np.int32), got["rgb"][rows].view(np.int32)), t
+            else:
+                assert (img[rows] == -7.0).all(), t
 
 
 @pytest.mark.parametrize("mode,depth", [(CPU, 2), (CL, 0)])

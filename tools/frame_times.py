@@ -12,7 +12,8 @@ fs = fs().to_flat()
 ex = HipExecutor(fs, device=0)
 out = np.zeros((H, W, 3), np.float32)
 for i in range(n):
-    r = ex.render(W, H, max_depth=depth, want_ids=False, time_kernels=True, out=out, algo=os.environ.get("ALGO"))
+    r = ex.render(W, H, max_depth=depth, want_ids=False, time_kernels=True, out=out, algo=os.environ.get("ALGO"),
+                  tile_step=int(os.environ.get("TILE_STEP", "1")))
     st = r["stats"]
     print(i, "total_ms", round(st.total_ms, 1), [round(x, 1) for x in st.kernel_ms], list(st.launches), "rays", st.rays, "exact_groups", list(st.exact_groups), "scanned_chunks", list(st.scanned_chunks),
           "rays p/b/s", st.rays_primary, st.rays_bounce, st.rays_shadow, "bvh_nodes", list(st.bvh_nodes), "bvh_tests", list(st.bvh_tests), "ovf", st.bvh_stack_overflows, flush=True)
