@@ -184,7 +184,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
     h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
-    CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 1));
+    CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 3));      // + one record: a one-triangle leaf is fetched as two
     CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
     CHK(upload<float4>(h, nullptr, 0, &nodes, 9 * (size_t)n + 1));
     B.tris = tris; B.ids = ids; B.nodes = nodes;
@@ -511,12 +511,23 @@ int launch_anyhit_lamp(hipexec *h, uint32_t lamp, const float4 *rays, uint32_t n
     }
 }
 
+// Rays owned by one block of a traversal kernel: `full` when the launch has work for the whole chip,
+// fewer (in whole waves) for a small launch, so that it still spreads over all compute units
+// instead of running a few long blocks on some of them.
+static uint32_t small_launch_share(uint32_t n, uint32_t full)
+{
+    const uint32_t want_blocks = 2048;                       // 8 per compute unit
+    uint32_t share = ((n / want_blocks) + 63u) & ~63u;
+    return std::max(64u, std::min(full, share));
+}
+
 template <int MODE>
 int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t n, float4 *hits, int klass_count)
 {
     if (h->bvh_refill) {
         // camera rays arrive in coherent 8x8 tiles (one ray per lane is best), bounce rays vary widely in length
-        uint32_t per_block = h->closest_per_block ? (uint32_t)h->closest_per_block : (klass_count == 0 ? 256u : 768u);
+        uint32_t per_block = h->closest_per_block ? (uint32_t)h->closest_per_block
+                                                  : small_launch_share(n, klass_count == 0 ? 256u : 768u);
         uint32_t blocks = (n + per_block - 1) / per_block;
         LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count,
                h->refill_closest | (h->sched_w << 8) | (int)(per_block << 16));
@@ -562,8 +573,9 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
     for (;; level++) {
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
         if (S.n_lamp && h->use_bvh) {
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), blocks_for(n), S, h->B, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
-                   h->lamp_words, h->d_cnt64);
+            const uint32_t per_block = small_launch_share(n, 256u);
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
+                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block);
         } else if (S.n_lamp) {
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
                    h->shadowq.as<float4>(), h->d_cnt32 + 1);

@@ -29,7 +29,7 @@ namespace rt {
 constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 2;
-constexpr int BVH_STACK = 32;                   // LDS stack entries per lane (a node pushes up to three)
+constexpr int BVH_STACK = 24;                   // LDS stack entries per lane (a node pushes up to three)
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
 constexpr float BVH_TIGHT = 4.0e-6f;
@@ -455,7 +455,7 @@ DEV uint32_t wave_take(bool want, uint32_t *next, uint32_t &idx) {
 constexpr int REFILL_BELOW = 44;       // active lanes below which a wave goes back to fetch rays
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bvh_closest_p(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest_p(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                        float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                        int klass, int refill_below)
 {
@@ -602,8 +602,8 @@ __global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const floa
 }
 
 // ---------------------------------------------------------------------------------------
-// k_bvh_shadow: shadow rays of one level without a global queue.  A block owns 256 rays of the
-// level.  Per group of SH_LAMPS lamps it evaluates the facing tests (ray_tracer.cpp:174-182 /
+// k_bvh_shadow: shadow rays of one level without a global queue.  A block owns `per_block` <= 256
+// rays of the level (fewer for small levels, so that the launch still covers the chip).  Per group of SH_LAMPS lamps it evaluates the facing tests (ray_tracer.cpp:174-182 /
 // ray_tracer_cl.cpp:138-143), compacts the (sample, lamp) pairs that cast a shadow ray into an
 // LDS list in lamp-major order (ballot + popcount, no global atomics), and then traces the
 // list 256 entries at a time, so waves stay full and their rays point at the same lamp from
@@ -613,10 +613,10 @@ __global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const floa
 constexpr int SH_LAMPS = 4;
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const float4 *__restrict__ rays,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
                                                     uint32_t *__restrict__ occl, uint32_t lw,
-                                                    unsigned long long *__restrict__ counters)
+                                                    unsigned long long *__restrict__ counters, uint32_t per_block)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ float Px[256], Py[256], Pz[256];
@@ -624,8 +624,8 @@ __global__ __launch_bounds__(256) void k_bvh_shadow(DScene S, DBvh B, const floa
     __shared__ uint16_t list[SH_LAMPS * 256];
     __shared__ uint32_t wcnt[SH_LAMPS * 4 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    uint32_t j = blockIdx.x * 256u + tid;
-    bool valid = j < n;
+    uint32_t j = blockIdx.x * per_block + tid;
+    bool valid = tid < per_block && j < n;
     f3 o, d; uint32_t s, aux;
     load_ray(rays, valid ? j : 0u, o, d, s, aux);
     float4 h = hits[valid ? j : 0u];
