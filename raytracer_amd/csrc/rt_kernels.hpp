@@ -838,8 +838,9 @@ __global__ __launch_bounds__(256) void k_shadowgen(DScene S, const float4 *__res
 
 // ---------------------------------------------------------------------------------------
 // k_shade: one thread per ray of the current level.  Writes local[s] = {colour, w} where
-// w = reflectionFactor if a bounce ray was queued and -1 otherwise, clears the occlusion bits
-// of s, and appends the bounce ray (ray_tracer.cpp:190-196) to next_rays.
+// w = reflectionFactor if the sample continues with a bounce ray and -1 otherwise, clears the
+// occlusion bits of s, and appends the bounce ray (ray_tracer.cpp:190-196) to next_rays unless
+// next_rays is null (then k_bounce has queued the bounce rays of this level already).
 // ---------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_shade(DScene S, const float4 *__restrict__ rays, const float4 *__restrict__ hits,
@@ -882,11 +883,41 @@ __global__ __launch_bounds__(256) void k_shade(DScene S, const float4 *__restric
         local[s] = make_float4(ret.x, ret.y, ret.z, w);
         for (uint32_t k = 0; k < lw; k++) occl[(size_t)s * lw + k] = 0u;
     }
-    if (spawn) {
+    if (spawn && next_rays) {
         __shared__ uint32_t append_scratch[5];
         uint32_t pos = block_append(bounce, next_count, append_scratch);
         if (bounce) store_ray(next_rays, pos, bo, bd, s, 0u);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bounce: the bounce rays of a level (ray_tracer.cpp:190-196) straight from its hits, before
+// the level is lit, so that the next level can be traced while this one's shadow rays and
+// shading run beside it.  The same expressions as in k_shade, hence the same rays.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bounce(DScene S, const float4 *__restrict__ rays, const float4 *__restrict__ hits,
+                                                uint32_t n, float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
+{
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    bool valid = j < n;
+    f3 o, d; uint32_t s, aux;
+    load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    float4 h = hits[valid ? j : 0u];
+    bool bounce = false;
+    f3 bo = mk(0.f, 0.f, 0.f), bd = mk(0.f, 0.f, 1.f);
+    if (valid && __float_as_int(h.w) >= 0) {
+        Surf sf = surface(S, o, d, h, false);
+        float kr = S.mat_b[sf.mat].z;
+        if (MODE == HIPEXEC_MODE_CPU && kr > RT_EPSF) {
+            bounce = true;
+            bo = sf.P;
+            bd = d - 2.0f * sf.N * dot(d, sf.N);
+        }
+    }
+    __shared__ uint32_t append_scratch[5];
+    uint32_t pos = block_append(bounce, next_count, append_scratch);
+    if (bounce) store_ray(next_rays, pos, bo, bd, s, 0u);
 }
 
 // ---------------------------------------------------------------------------------------

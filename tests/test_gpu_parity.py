@@ -164,6 +164,28 @@ def test_two_lane_frame(backends):
                 assert (img[rows] == -7.0).all(), t
 
 
+@pytest.mark.parametrize("overlap", ["0", "2"])
+def test_levels_on_one_or_two_streams(overlap, monkeypatch):
+    """HIPEXEC_OVERLAP=2 lights every level on a side stream while the next one is traced, 0 keeps one
+    stream per lane; the frame, the hit ids and the ray counts are those of the oracle either way."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    monkeypatch.setenv("HIPEXEC_OVERLAP", overlap)
+    fs = scenegen.small_variant("mirror").to_flat()
+    W, H = 48, 132
+    orc = Oracle(fs)
+    with HipExecutor(fs, device=0) as ex:
+        ref = orc.render(W, H, mode=CPU, max_depth=4, tone=0, n_threads=8)
+        for _ in range(2):                                  # the second frame reuses every buffer and event
+            got = ex.render(W, H, mode=CPU, max_depth=4, tone=False, algo="bvh")
+            assert np.array_equal(got["ids"], ref["ids"])
+            assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+            for k in ("rays_primary", "rays_bounce", "rays_shadow"):
+                assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
+        rays = _random_rays(fs, 500, 11)
+        assert ulp_diff(ex.trace_rays(rays, CPU, max_depth=3), orc.trace_rays(rays, CPU, max_depth=3)).max() <= 4
+
+
 @pytest.mark.parametrize("mode,depth", [(CPU, 2), (CL, 0)])
 def test_progressive_render_delivers_the_same_frame_in_steps(backends, mode, depth):
     fs, ex, orc = backends("c2")
