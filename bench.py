@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test
-F_NODE = 96.0                        # FLOP per visited hierarchy node (two enlarged-box slab tests, see bvh_box)
+F_NODE = 190.0                       # FLOP per visited hierarchy node (cone term + four enlarged-box slab tests of 46, see bvh_box)
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA)
 
 WORKLOADS = {
