@@ -103,14 +103,15 @@ struct hipexec {
     // is split into even and odd tiles that the two lanes trace concurrently, so that the thinly
     // populated tail of one lane's kernels (a few very long rays) overlaps the other lane's work.
     int win_lo = 0, win_hi = INT_MAX;         // window into the call's tile list (progressive rendering)
-    hipexec *helper = nullptr;
-    bool is_helper = false, helper_used = false;
+    std::vector<hipexec *> helpers;           // further lanes of this executor (own streams, buffers, counters; no scene memory)
+    bool is_helper = false;
+    int lanes_used = 1;                       // lanes of the call in progress
+    int max_lanes = 2;                        // HIPEXEC_LANES
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // side stream of this lane: lights a level (shadow rays, shading) while the next level is traced on `stream`
     hipStream_t side = nullptr;
     hipEvent_t ev_hits[2] = {nullptr, nullptr}, ev_lit[2] = {nullptr, nullptr};
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
-    std::string helper_err;
 };
 
 namespace {
@@ -452,7 +453,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
     h->acc.rays_shadow += h->h_cnt64[14];
     h->acc.bvh_stack_overflows = h->h_cnt64[15];
     h->acc.algorithm = h->use_bvh ? HIPEXEC_ALGO_BVH : HIPEXEC_ALGO_SCAN;
-    h->acc.lanes = (h->helper_used && h->helper) ? 2u : 1u;
+    h->acc.lanes = (uint32_t)h->lanes_used;
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
     for (TimedLaunch &t : h->timed) {
         float ms = 0.f;
@@ -462,13 +463,13 @@ int call_end(hipexec *h, hipexec_stats *stats)
     }
     h->timed.clear();
     h->call_open = false;
-    if (h->helper_used && h->helper && h->helper->call_open) {
-        // the second lane's share of the frame: its counters and kernel times are added to this call's
-        hipexec *g = h->helper;
-        h->helper_used = false;
+    // the other lanes' shares of the frame: their counters and kernel times are added to this call's
+    for (hipexec *g : h->helpers) {
+        if (!g->call_open) continue;
         CHK(call_end(g, nullptr));
         add_stats(h->acc, g->acc);
     }
+    h->lanes_used = 1;
     if (stats) *stats = h->acc;
     return HIPEXEC_OK;
 }
@@ -761,38 +762,48 @@ int call_begin(hipexec *h, bool timing, uint32_t flags);
 
 int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
 {
-    hipexec *g = h->helper;
-    h->helper_used = false;
-    // Two lanes pay when bounce levels exist (their small, long-tailed launches overlap the other lane's
-    // large ones: C2 -8 %, C3 -6 %); a depth-0 frame is two large uniform kernels and gains nothing.
+    h->lanes_used = 1;
+    // Several lanes pay when bounce levels exist (their small, long-tailed launches overlap the other lanes'
+    // large ones); a depth-0 frame is two large uniform kernels and gains nothing.  Lane k of L traces the
+    // tiles k, k + L, ... of the call's tile list; at least 4 tiles per lane.
     const bool bounces = c->mode == HIPEXEC_MODE_CPU && c->max_depth > 0;
     const int n_window = std::min(n_tiles_of(c), h->win_hi) - h->win_lo;
-    if (!h->use_bvh || !g || !bounces || n_window < 8) return render_sub(h, c, d_rgba, d_ids, 0, 1);
-    g->win_lo = h->win_lo; g->win_hi = h->win_hi;
-    // fork: the helper's stream starts after everything queued on this executor's stream so far
-    h->helper_used = true;
-    g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
-    g->bvh_refill = h->bvh_refill; g->bvh_default = true;
+    const int L = std::min({(int)h->helpers.size() + 1, h->max_lanes, n_window / 4});
+    if (!h->use_bvh || !bounces || L < 2) return render_sub(h, c, d_rgba, d_ids, 0, 1);
+    h->lanes_used = L;
+    // fork: the other lanes' streams start after everything queued on this executor's stream so far
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-    HIPCHK(hipStreamWaitEvent(g->stream, h->ev_fork, 0));
-    int rc_helper = HIPEXEC_OK;
-    std::thread worker([&]() {
-        rc_helper = [&]() -> int {
-            CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & HIPEXEC_FLAG_BILINEAR)));
-            return render_sub(g, c, d_rgba, d_ids, 1, 2);
-        }();
-        if (rc_helper != HIPEXEC_OK) h->helper_err = g_err;          // g_err is per thread
-    });
-    int rc = render_sub(h, c, d_rgba, d_ids, 0, 2);
-    worker.join();
-    // join: later work on this executor's stream waits for the helper's kernels
-    if (rc_helper == HIPEXEC_OK) {
-        HIPCHK(hipEventRecord(h->ev_join, g->stream));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    } else {
-        (void)hipStreamSynchronize(g->stream);
-        g->call_open = false;
-        if (rc == HIPEXEC_OK) { snprintf(g_err, sizeof g_err, "%s", h->helper_err.c_str()); rc = rc_helper; }
+    std::vector<int> rcs((size_t)L, HIPEXEC_OK);
+    std::vector<std::string> errs((size_t)L);
+    std::vector<std::thread> workers;
+    for (int k = 1; k < L; k++) {
+        hipexec *g = h->helpers[(size_t)k - 1];
+        g->win_lo = h->win_lo; g->win_hi = h->win_hi;
+        g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
+        g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
+        workers.emplace_back([&, g, k]() {
+            rcs[(size_t)k] = [&]() -> int {
+                HIPCHK(hipSetDevice(g->device));
+                HIPCHK(hipStreamWaitEvent(g->stream, h->ev_fork, 0));
+                CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & HIPEXEC_FLAG_BILINEAR)));
+                return render_sub(g, c, d_rgba, d_ids, k, L);
+            }();
+            if (rcs[(size_t)k] != HIPEXEC_OK) errs[(size_t)k] = g_err;          // g_err is per thread
+        });
+    }
+    int rc = render_sub(h, c, d_rgba, d_ids, 0, L);
+    for (std::thread &w : workers) w.join();
+    // join: later work on this executor's stream waits for the other lanes' kernels
+    for (int k = 1; k < L; k++) {
+        hipexec *g = h->helpers[(size_t)k - 1];
+        if (rcs[(size_t)k] == HIPEXEC_OK) {
+            HIPCHK(hipEventRecord(g->ev_join, g->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream, g->ev_join, 0));
+        } else {
+            (void)hipStreamSynchronize(g->stream);
+            g->call_open = false;
+            if (rc == HIPEXEC_OK) { snprintf(g_err, sizeof g_err, "%s", errs[(size_t)k].c_str()); rc = rcs[(size_t)k]; }
+        }
     }
     return rc;
 }
@@ -886,16 +897,16 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each
         // wave reads only the chunks it needs and the scalar path wins
         if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
-        const char *lanes = getenv("HIPEXEC_LANES");                 // "1": no second lane
-        if (h->bvh_ok && !(lanes && atoi(lanes) == 1)) {
+        if (const char *e = getenv("HIPEXEC_LANES")) h->max_lanes = std::max(1, std::min(8, atoi(e)));      // 1: no further lanes
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int k = 1; h->bvh_ok && k < h->max_lanes; k++) {
             hipexec *g = new (std::nothrow) hipexec();
             if (!g) return fail(HIPEXEC_E_NOMEM, "out of host memory");
-            h->helper = g;
+            h->helpers.push_back(g);
             g->is_helper = true; g->device = device;
             g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words;     // the scene stays owned by h
             CHK(create_lane_resources(g, scene->n_lamp));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
         }
         return HIPEXEC_OK;
     }();
@@ -908,7 +919,8 @@ void hipexec_destroy(hipexec_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->helper) { hipexec_destroy(h->helper); h->helper = nullptr; }      // owns no scene memory
+    for (hipexec *g : h->helpers) hipexec_destroy(g);                          // they own no scene memory
+    h->helpers.clear();
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamSynchronize(h->stream);

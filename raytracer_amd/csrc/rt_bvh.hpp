@@ -189,8 +189,8 @@ DEV float4 bvh_cone(float4 nl, float4 nh) {
     return make_float4(a.x * (ca * k), a.y * (ca * k), a.z * (ca * k), sa * k);
 }
 
-// A node lists its grandchildren (a child that is a leaf stays one slot) and carries one cone, that
-// of all its triangles.  (A cone per slot prunes a little more but the larger record costs more
+// A node lists up to four descendants (its children, the larger ones opened once more) and carries one
+// cone, that of all its triangles.  (A cone per slot prunes a little more but the larger record costs more
 // than that saves.)
 __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ range,
                             const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
@@ -198,11 +198,22 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < 2 || i >= n - 1) return;
-    uint32_t slot[4]; int ns = 0;
-    for (int side = 0; side < 2; side++) {
-        uint32_t c = child[2 * i + side];
-        if (bvh_ref_of(c, n, range) & BVH_LEAF) slot[ns++] = c;
-        else { slot[ns++] = child[2 * c]; slot[ns++] = child[2 * c + 1]; }
+    // start from the two children and twice replace the inner slot with the largest box by its two children
+    uint32_t slot[4] = {child[2 * i], child[2 * i + 1], 0u, 0u};
+    int ns = 2;
+    for (int round = 0; round < 2; round++) {
+        int pick = -1; float best_area = -1.0f;
+        for (int k = 0; k < ns; k++) {
+            if (bvh_ref_of(slot[k], n, range) & BVH_LEAF) continue;
+            float4 lo = box_lo[slot[k]], hi = box_hi[slot[k]];
+            float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+            float area = dx * dy + dy * dz + dz * dx;
+            if (area > best_area) { best_area = area; pick = k; }
+        }
+        if (pick < 0) break;
+        uint32_t c = slot[pick];
+        slot[pick] = child[2 * c];
+        slot[ns++] = child[2 * c + 1];
     }
     float4 *N = nodes + 9 * (size_t)i;
     for (int k = 0; k < 4; k++) {
