@@ -159,8 +159,9 @@ typedef struct hipexec_stats {
     uint64_t bvh_stack_overflows; /* rays whose traversal stack overflowed and that were finished by a
                                      linear scan instead (same result, slow); expected 0          */
     uint32_t algorithm;           /* HIPEXEC_ALGO_* the call ran with                             */
-    uint32_t lanes;               /* 1, or 2 when the frame was split over two concurrent streams; kernel_ms
-                                     then sums overlapping launches and can exceed total_ms              */
+    uint32_t lanes;               /* concurrent lanes (streams with their own buffers) the frame was split
+                                     over: 1, or 2 by default for frames with bounce levels; kernel_ms then
+                                     sums overlapping launches and can exceed total_ms                    */
     uint32_t launches[HIPEXEC_K_COUNT];
     float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */
     float    total_ms;                     /* HIP-event time of the whole call on its stream */
