@@ -13,6 +13,10 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -60,6 +64,59 @@ struct Buf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Host thread of a further lane.  It lives as long as its executor: starting a std::thread per frame
+// delayed the lane's first kernel by 0.2 ms.  After a job the thread polls for the next one for a
+// short while (a render loop submits the next frame within that time) before it blocks.
+struct LaneWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    std::atomic<int> state{0};               // 0 idle, 1 job posted, 2 running
+    bool quit = false;
+    void run() {
+        for (;;) {
+            for (int spin = 0; spin < 20000 && state.load(std::memory_order_acquire) != 1; spin++) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1 || quit; });
+                if (quit) return;
+                state.store(2, std::memory_order_release);
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                state.store(0, std::memory_order_release);
+            }
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j) {
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            state.store(1, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 0; });
+    }
+    void stop() {
+        if (!th.joinable()) return;
+        wait();
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
+
 struct TimedLaunch { hipEvent_t a, b; int klass; };
 
 constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte shadow rays per batch
@@ -105,6 +162,7 @@ struct hipexec {
     int win_lo = 0, win_hi = INT_MAX;         // window into the call's tile list (progressive rendering)
     std::vector<hipexec *> helpers;           // further lanes of this executor (own streams, buffers, counters; no scene memory)
     bool is_helper = false;
+    LaneWorker *worker = nullptr;             // host thread of a helper lane
     int lanes_used = 1;                       // lanes of the call in progress
     int max_lanes = 2;                        // HIPEXEC_LANES
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -775,13 +833,12 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
     std::vector<int> rcs((size_t)L, HIPEXEC_OK);
     std::vector<std::string> errs((size_t)L);
-    std::vector<std::thread> workers;
     for (int k = 1; k < L; k++) {
         hipexec *g = h->helpers[(size_t)k - 1];
         g->win_lo = h->win_lo; g->win_hi = h->win_hi;
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
         g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
-        workers.emplace_back([&, g, k]() {
+        g->worker->submit([&, g, k]() {
             rcs[(size_t)k] = [&]() -> int {
                 HIPCHK(hipSetDevice(g->device));
                 HIPCHK(hipStreamWaitEvent(g->stream, h->ev_fork, 0));
@@ -792,7 +849,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
         });
     }
     int rc = render_sub(h, c, d_rgba, d_ids, 0, L);
-    for (std::thread &w : workers) w.join();
+    for (int k = 1; k < L; k++) h->helpers[(size_t)k - 1]->worker->wait();
     // join: later work on this executor's stream waits for the other lanes' kernels
     for (int k = 1; k < L; k++) {
         hipexec *g = h->helpers[(size_t)k - 1];
@@ -904,6 +961,8 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
             if (!g) return fail(HIPEXEC_E_NOMEM, "out of host memory");
             h->helpers.push_back(g);
             g->is_helper = true; g->device = device;
+            g->worker = new (std::nothrow) LaneWorker();
+            if (!g->worker) return fail(HIPEXEC_E_NOMEM, "out of host memory");
             g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words;     // the scene stays owned by h
             CHK(create_lane_resources(g, scene->n_lamp));
             HIPCHK(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
@@ -918,6 +977,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
 void hipexec_destroy(hipexec_t *h)
 {
     if (!h) return;
+    if (h->worker) { h->worker->stop(); delete h->worker; h->worker = nullptr; }
     (void)hipSetDevice(h->device);
     for (hipexec *g : h->helpers) hipexec_destroy(g);                          // they own no scene memory
     h->helpers.clear();
