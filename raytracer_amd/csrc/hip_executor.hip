@@ -122,7 +122,8 @@ struct TimedLaunch { hipEvent_t a, b; int klass; };
 constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte shadow rays per batch
 constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk of the batch entry points
 constexpr uint64_t BATCH_MAX_SAMPLES = 64ull << 20;          // samples per batch of a frame without a shadow queue
-constexpr int N_CNT64 = 16;                                  // device counters, see call_end
+constexpr uint32_t TAIL_MAX_RAYS = 300000u;                    // see use_tail
+constexpr int N_CNT64 = 17;                                  // device counters, see call_end
 
 }  // namespace
 
@@ -169,6 +170,7 @@ struct hipexec {
     // side stream of this lane: lights a level (shadow rays, shading) while the next level is traced on `stream`
     hipStream_t side = nullptr;
     hipEvent_t ev_hits[2] = {nullptr, nullptr}, ev_lit[2] = {nullptr, nullptr};
+    uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
 };
 
@@ -510,6 +512,10 @@ int call_end(hipexec *h, hipexec_stats *stats)
     }
     h->acc.rays_shadow += h->h_cnt64[14];
     h->acc.bvh_stack_overflows = h->h_cnt64[15];
+    // bounce rays generated inside k_bvh_tail were never counted on the host
+    h->acc.rays_bounce += h->h_cnt64[16];
+    h->acc.tests_tri_closest += h->h_cnt64[16] * (uint64_t)h->S.n_tri;
+    h->acc.tests_sph_closest += h->h_cnt64[16] * (uint64_t)h->S.n_sph;
     h->acc.algorithm = h->use_bvh ? HIPEXEC_ALGO_BVH : HIPEXEC_ALGO_SCAN;
     h->acc.lanes = (uint32_t)h->lanes_used;
     HIPCHK(hipEventElapsedTime(&h->acc.total_ms, h->ev_begin, h->ev_end));
@@ -625,6 +631,21 @@ int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 
 constexpr uint32_t OVERLAP_MAX_SAMPLES = 2500000u;
 
+// k_bvh_tail takes over when the queue of a level is small and at least two levels remain (for the last
+// level alone the separate, coherent kernels are as good).
+bool use_tail(const hipexec *h, uint32_t n_rays, int level, int depth)
+{
+    return h->use_bvh && h->bvh_refill && n_rays <= h->tail_max && level < depth;
+}
+
+template <int MODE>
+int launch_tail(hipexec *h, const float4 *rays, uint32_t n, int level, int depth, size_t stride)
+{
+    LAUNCH(HIPEXEC_K_CLOSEST, (k_bvh_tail<MODE>), blocks_for(n), h->S, h->B, rays, n, level, depth, h->local.as<float4>(), stride,
+           h->d_cnt64);
+    return HIPEXEC_OK;
+}
+
 // trace_levels for the hierarchy with reflections, on two streams.  The bounce rays of a level depend
 // only on its hits, so k_bounce queues them at once and the main stream goes on to trace the next
 // level, while the side stream casts this level's shadow rays and shades it.  The small, long-tailed
@@ -641,6 +662,7 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
     hipStream_t main_s = h->stream, side_s = h->side;
     uint32_t n = n0;
     int level = 0;
+    bool tail = false;
     for (;; level++) {
         const bool spawn = level < depth;
         HIPCHK(hipEventRecord(h->ev_hits[level & 1], main_s));               // this level's hits are complete
@@ -668,11 +690,16 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
         h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
         cur_rays = ray_buf[(level + 1) & 1];
         cur_hits = hit_buf[(level + 1) & 1];
+        if (use_tail(h, nn, level + 1, depth)) {
+            CHK(launch_tail<MODE>(h, cur_rays, nn, level + 1, depth, stride));
+            tail = true;
+            break;
+        }
         CHK(launch_bvh_closest<MODE>(h, HIPEXEC_K_CLOSEST, cur_rays, nn, cur_hits, 1));
         n = nn;
     }
     HIPCHK(hipStreamWaitEvent(main_s, h->ev_lit[level & 1], 0));             // the side stream is in order: every level is lit
-    *levels_used = level + 1;
+    *levels_used = tail ? depth + 1 : level + 1;
     return HIPEXEC_OK;
 }
 
@@ -720,6 +747,11 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
         h->acc.rays_bounce += nn;
         h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
         h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
+        if (use_tail(h, nn, level + 1, depth)) {
+            CHK(launch_tail<MODE>(h, next_rays, nn, level + 1, depth, stride));
+            *levels_used = depth + 1;
+            return HIPEXEC_OK;
+        }
         CHK(launch_closest<MODE>(h, next_rays, nn, h->hitN.as<float4>()));
         std::swap(cur_rays, next_rays);
         cur_hits = h->hitN.as<float4>();
@@ -901,6 +933,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
     h->n_cnt32 = std::max(8u, n_lamp + 1u);
     HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));

@@ -712,4 +712,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     bvh_count(counters, 2, n_nodes, n_tris, n_rays);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_bvh_tail: the remaining recursion levels of a small ray queue in one launch.  A lane follows its
+// ray from level `level0` to the end of its path (closest hit, shadow rays, shading, bounce, and so
+// on), writing local[level][s] exactly as k_shade does.  Used when the queue of a level is so small that
+// every separate launch would cost its floor (the longest ray) while most of the chip idles: the floors of
+// all remaining levels then collapse into one.  Same device functions, same operation order per
+// sample, hence the same bits as the level-by-level kernels.
+// counters[16] += bounce rays generated here (levels above level0).
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_tail(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n, int level0,
+                                                  int depth, float4 *__restrict__ local, size_t level_stride,
+                                                  unsigned long long *__restrict__ counters)
+{
+    __shared__ uint32_t stack[BVH_STACK][256];
+    uint32_t *stk = &stack[0][threadIdx.x];
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    bool alive = j < n;
+    f3 o, d; uint32_t s, aux;
+    load_ray(rays, alive ? j : 0u, o, d, s, aux);
+    uint32_t nodes_c = 0, tris_c = 0, nodes_s = 0, tris_s = 0, n_shadow = 0, n_bounce = 0;
+    for (int level = level0; alive; level++) {
+        Best sb = spheres_closest<MODE>(S, o, d);
+        Best tb = best_none();
+        TRay r = tray_make(S, B, o, d);
+        bvh_traverse<MODE, false>(B, r, o, d, sb.id >= 0 ? sb.t : __builtin_inff(), tb, stk, nodes_c, tris_c);
+        float4 h = merge_hits<MODE>(S, tb, sb);
+        f3 ret; float w = -1.0f;
+        if (__float_as_int(h.w) < 0) {
+            f3 hz = mk(S.horizon[0], S.horizon[1], S.horizon[2]);
+            ret = (MODE == HIPEXEC_MODE_CL) ? (mk(0.f, 0.f, 0.f) + hz) : hz;
+            alive = false;
+        } else {
+            Surf sf = surface(S, o, d, h, true);
+            ret = (MODE == HIPEXEC_MODE_CL) ? mk(0.f, 0.f, 0.f) : mk(S.ambient[0], S.ambient[1], S.ambient[2]);
+            for (uint32_t l = 0; l < S.n_lamp; l++) {
+                float4 lp = S.lamp[l];
+                f3 toLamp = xyz(lp) - sf.P;
+                float dotWithLamp = dot(toLamp, sf.N);
+                float dotWithDir = dot(d, sf.N);
+                if (!casts_shadow_ray<MODE>(dotWithDir, dotWithLamp)) continue;
+                n_shadow++;
+                bool occluded = false;
+                for (uint32_t k = 0; k < S.n_sph && !occluded; k++) {
+                    float4 sp = S.sph[k];
+                    float t;
+                    occluded = sph_exact<MODE>(sf.P, toLamp, xyz(sp), sp.w, t);
+                }
+                if (!occluded) {
+                    TRay rs = tray_make(S, B, sf.P, toLamp);
+                    Best none = best_none();
+                    occluded = bvh_traverse<MODE, true>(B, rs, sf.P, toLamp, __builtin_inff(), none, stk, nodes_s, tris_s);
+                }
+                if (occluded) continue;
+                ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
+            }
+            if (MODE == HIPEXEC_MODE_CPU && level < depth && sf.kr > RT_EPSF) {
+                w = sf.kr;
+                f3 bd = d - 2.0f * sf.N * dot(d, sf.N);
+                o = sf.P; d = bd;
+                n_bounce++;
+            } else alive = false;
+        }
+        local[(size_t)level * level_stride + s] = make_float4(ret.x, ret.y, ret.z, w);
+    }
+    bvh_count(counters, 1, nodes_c, tris_c, 0u);
+    __syncthreads();                        // bvh_count's LDS sums are reused by the second call
+    bvh_count(counters, 2, nodes_s, tris_s, n_shadow);
+    unsigned long long nb = wave_sum_u64(n_bounce);
+    if ((threadIdx.x & 63u) == 0 && nb) atomicAdd(&counters[16], nb);
+}
+
 }  // namespace rt

@@ -164,13 +164,17 @@ def test_two_lane_frame(backends):
                 assert (img[rows] == -7.0).all(), t
 
 
+@pytest.mark.parametrize("tail_max", ["0", "300000"])
 @pytest.mark.parametrize("overlap", ["0", "2"])
-def test_levels_on_one_or_two_streams(overlap, monkeypatch):
+def test_levels_on_one_or_two_streams(overlap, tail_max, monkeypatch):
     """HIPEXEC_OVERLAP=2 lights every level on a side stream while the next one is traced, 0 keeps one
-    stream per lane; the frame, the hit ids and the ray counts are those of the oracle either way."""
+    stream per lane; HIPEXEC_TAIL_MAX=0 traces every level with its own launches, otherwise small ray
+    queues are followed to the end of their paths by one kernel.  The frame, the hit ids and the ray
+    counts are those of the oracle in every combination."""
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
     monkeypatch.setenv("HIPEXEC_OVERLAP", overlap)
+    monkeypatch.setenv("HIPEXEC_TAIL_MAX", tail_max)
     fs = scenegen.small_variant("mirror").to_flat()
     W, H = 48, 132
     orc = Oracle(fs)
@@ -180,7 +184,7 @@ def test_levels_on_one_or_two_streams(overlap, monkeypatch):
             got = ex.render(W, H, mode=CPU, max_depth=4, tone=False, algo="bvh")
             assert np.array_equal(got["ids"], ref["ids"])
             assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
-            for k in ("rays_primary", "rays_bounce", "rays_shadow"):
+            for k in ("rays_primary", "rays_bounce", "rays_shadow", "tests_tri_closest", "tests_sph_closest"):
                 assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
         rays = _random_rays(fs, 500, 11)
         assert ulp_diff(ex.trace_rays(rays, CPU, max_depth=3), orc.trace_rays(rays, CPU, max_depth=3)).max() <= 4
