@@ -107,8 +107,8 @@ def cpu_baseline(fs, W, H, depth, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--algo", default="bvh", choices=["bvh", "scan", "brute"],
                     help="bvh: hierarchy traversal (default); scan: index-order scans with chunk culling; "
