@@ -34,7 +34,7 @@ WORKLOADS = {
 }
 
 KNAMES = {"scan": ["k_primary", "k_closest", "k_anyhit_lamp", "shade/resolve"],
-          "bvh": ["k_bvh_closest_p", "k_bvh_closest_p", "k_bvh_shadow", "shade/resolve"]}
+          "bvh": ["k_bvh_closest_pk", "k_bvh_closest_p", "k_bvh_shadow", "shade/resolve"]}
 KLABEL = ["camera rays", "bounce rays", "shadow rays", "shading"]
 
 

@@ -170,6 +170,7 @@ struct hipexec {
     // side stream of this lane: lights a level (shadow rays, shading) while the next level is traced on `stream`
     hipStream_t side = nullptr;
     hipEvent_t ev_hits[2] = {nullptr, nullptr}, ev_lit[2] = {nullptr, nullptr};
+    bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
 };
@@ -594,7 +595,10 @@ static uint32_t small_launch_share(uint32_t n, uint32_t full)
 template <int MODE>
 int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t n, float4 *hits, int klass_count)
 {
-    if (h->bvh_refill) {
+    if (h->packet && klass_count == 0) {
+        // camera rays: the 64 rays of a wave are one 8x8-pixel tile of one sub-sample and walk the hierarchy as a packet
+        LAUNCH(klass_time, (k_bvh_closest_pk<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count);
+    } else if (h->bvh_refill) {
         // camera rays arrive in coherent 8x8 tiles (one ray per lane is best), bounce rays vary widely in length
         uint32_t per_block = h->closest_per_block ? (uint32_t)h->closest_per_block
                                                   : small_launch_share(n, klass_count == 0 ? 256u : 768u);
@@ -933,6 +937,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (const char *e = getenv("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
     h->n_cnt32 = std::max(8u, n_lamp + 1u);

@@ -429,6 +429,117 @@ DEV bool bvh_linear(const DBvh &B, f3 o, f3 d, Best &best, uint32_t &n_tris) {
     return found;
 }
 
+// ---------------------------------------------------------------------------------------
+// Packet form of the traversal for the 64 rays of a wave that travel together (the camera rays of an
+// 8x8-pixel tile, shadow rays from neighbouring surface points to one lamp).  The wave walks ONE path
+// through the hierarchy: node and leaf records are fetched once per wave through the scalar cache, every
+// lane tests them against its own ray, and the walk enters a slot if any lane's ray may.  Each stack
+// entry carries the mask of the lanes that asked for it, so a lane evaluates exactly the boxes and exact
+// tests its own walk would have (in a different order, which the winner rule does not depend on).
+// The stack (node, 64-bit lane mask) is per wave, in LDS.  Returns false if that stack overflowed; the caller then
+// repeats the rays with the per-lane traversal (closest: `best` may hold valid candidates and stays usable).
+// ---------------------------------------------------------------------------------------
+constexpr int PK_STACK = 4 * BVH_STACK;   // entries of the wave's stack: up to three pushes per level
+
+template <int MODE, bool ANY>
+DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float &limit, Best &best, uint32_t &found,
+                    uint32_t *pst, uint32_t &n_nodes, uint32_t &n_tris)
+{
+    const float4 *__restrict__ T = B.tris;
+    const float4 *__restrict__ NB = B.nodes;
+    const int lane = lane_id();
+    unsigned long long alive = __ballot(valid && !(ANY && found));
+    uint32_t node = B.root;
+    unsigned long long mask = alive;
+    int sp = 0;
+    bool ok = true;
+    const int pk_limit = B.stack_limit * (PK_STACK / BVH_STACK);     // PK_STACK unless the test hook shortens the stacks
+    for (;;) {
+        // node and mask are the same in every lane; saying so lets the records below come through the scalar cache
+        node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+        mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask);
+        mask &= alive;
+        if (mask == 0ull || node == BVH_NONE) {
+            if (sp == 0) break;
+            sp--;
+            node = (uint32_t)__builtin_amdgcn_readfirstlane((int)pst[sp]);
+            uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)pst[PK_STACK + sp]);
+            uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)pst[2 * PK_STACK + sp]);
+            mask = ((unsigned long long)mhi << 32) | mlo;
+            continue;
+        }
+        const bool mine = ((mask >> lane) & 1ull) != 0ull;
+        if (node & BVH_LEAF) {
+            const uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
+            for (uint32_t k = first; k < first + cnt; k++) {
+                float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
+                if (mine && !(ANY && found)) {
+                    n_tris++;
+                    float t, u, v;
+                    if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
+                        if (ANY) found = 1u;
+                        else {
+                            best_update_indexed(best, t, u, v, (int)B.ids[k]);
+                            limit = fminf(limit, best.t);
+                        }
+                    }
+                }
+            }
+            if (ANY) alive &= ~__ballot(found != 0u);
+            node = BVH_NONE;
+        } else {
+            const float4 *N = NB + 9 * (size_t)node;
+            float4 lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { lo[k] = N[k]; hi[k] = N[4 + k]; }
+            float4 cone = N[8];
+            float tk[4]; bool hk[4] = {false, false, false, false};
+            if (mine) {
+                n_nodes++;
+                float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
+                float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
+            }
+            // the slot that the first interested lane would enter first is walked next, the others are pushed
+            unsigned long long votes[4]; float rep[4];
+            int which = -1; float rep_best = __builtin_inff();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                votes[k] = __ballot(hk[k]);
+                rep[k] = __builtin_inff();
+                if (votes[k]) {
+                    int leader = __ffsll((long long)votes[k]) - 1;
+                    rep[k] = fminf(__shfl(tk[k], leader), 3.0e38f);
+                    if (which < 0 || rep[k] < rep_best) { which = k; rep_best = rep[k]; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (votes[k] != 0ull && k != which) {
+                    if (sp < pk_limit) {
+                        if (lane == 0) {
+                            pst[sp] = __float_as_uint(hi[k].w);
+                            pst[PK_STACK + sp] = (uint32_t)votes[k];
+                            pst[2 * PK_STACK + sp] = (uint32_t)(votes[k] >> 32);
+                        }
+                        sp++;
+                    } else ok = false;
+                }
+            }
+            if (!ok) break;
+            if (which >= 0) {
+                uint32_t nx = 0u; unsigned long long nm = 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k == which) { nx = __float_as_uint(hi[k].w); nm = votes[k]; }
+                node = nx; mask = nm;
+            } else node = BVH_NONE;
+        }
+    }
+    return ok;
+}
+
 // One ray per lane, start to finish.  ANY = false: closest triangle hit into `best` (limit =
 // largest t still of interest, e.g. the sphere winner).  ANY = true: returns whether any triangle
 // is hit.  `stk` points at this lane's column of the LDS stack (entries 256 words apart).
@@ -580,6 +691,29 @@ __global__ __launch_bounds__(256) void k_bvh_closest(DScene S, DBvh B, const flo
         bvh_traverse<MODE, false>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris);
         hits[j] = merge_hits<MODE>(S, tb, sb);
     }
+    bvh_count(counters, klass, n_nodes, n_tris, 0u);
+}
+
+// Closest hits of rays that arrive in coherent groups of 64 (camera rays: one 8x8-pixel tile per wave): packet walk.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bvh_closest_pk(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+                                                        float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
+                                                        int klass)
+{
+    __shared__ uint32_t pstack[4][3 * PK_STACK];
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    bool valid = j < n;
+    f3 o, d; uint32_t s, aux;
+    load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    valid = valid && aux == 0u;
+    uint32_t n_nodes = 0, n_tris = 0, found = 0;
+    Best sb = spheres_closest<MODE>(S, o, d);
+    Best tb = best_none();
+    TRay r = tray_make(S, B, o, d);
+    float limit = sb.id >= 0 ? sb.t : __builtin_inff();
+    bool ok = bvh_packet<MODE, false>(B, r, o, d, valid, limit, tb, found, pstack[threadIdx.x >> 6], n_nodes, n_tris);
+    if (!ok && valid) { bvh_linear<MODE, false>(B, o, d, tb, n_tris); n_nodes |= 0x80000000u; }
+    if (valid) hits[j] = merge_hits<MODE>(S, tb, sb);
     bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
 

@@ -164,6 +164,25 @@ def test_two_lane_frame(backends):
                 assert (img[rows] == -7.0).all(), t
 
 
+@pytest.mark.parametrize("packet", ["0", "1"])
+def test_camera_rays_as_packets_or_per_lane(packet, backends, monkeypatch):
+    """HIPEXEC_PACKET=1 (default) walks the hierarchy once per 8x8-pixel tile of camera rays, 0 once per ray;
+    hit ids and colours are the same (the walk order, and with it the number of tests the shrinking limit
+    prunes, differs)."""
+    from raytracer_amd.executor import HipExecutor
+    monkeypatch.setenv("HIPEXEC_PACKET", packet)
+    for name in ("c2", "soup", "mirror"):
+        fs, ex_default, orc = backends(name)
+        with HipExecutor(fs, device=0) as ex:
+            for mode, depth in ((CPU, 2), (CL, 0)):
+                ref = orc.render(61, 43, mode=mode, max_depth=depth, tone=0, n_threads=8)
+                got = ex.render(61, 43, mode=mode, max_depth=depth, tone=False, algo="bvh")
+                assert np.array_equal(got["ids"], ref["ids"]), name
+                assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+                base = ex_default.render(61, 43, mode=mode, max_depth=depth, tone=False, algo="bvh")
+                assert np.array_equal(got["rgb"].view(np.int32), base["rgb"].view(np.int32))
+
+
 @pytest.mark.parametrize("tail_max", ["0", "300000"])
 @pytest.mark.parametrize("overlap", ["0", "2"])
 def test_levels_on_one_or_two_streams(overlap, tail_max, monkeypatch):
