@@ -59,6 +59,30 @@ def test_c2_full_size_depth3():
     _check_blocks(fs, a, W, H, depth, _abi.HIPEXEC_MODE_CPU, _blocks(W, H, 5, 4), lin)
 
 
+def test_c3_4k_depth5_shards_of_eight():
+    """Benchmark config 3: the C2 scene at 3840x2160 with depth-5 reflections, as the 8-GPU partition
+    renders it: eight interleaved shards (each small enough for the side-stream and tail-kernel paths)
+    compose bit for bit to the unsharded frame, counters add up, and a grid of blocks matches the oracle."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = scenegen.scene_c2().to_flat()
+    W, H, depth = 3840, 2160, 5
+    with HipExecutor(fs, device=0) as ex:
+        a = ex.render(W, H, max_depth=depth)
+        img = np.full((H, W, 3), -1, np.float32)
+        rays = 0
+        for r in range(8):
+            p = ex.render(W, H, max_depth=depth, tile_first=r, tile_step=8, out=img, want_ids=False)
+            rays += p["stats"].rays
+        assert np.array_equal(img.view(np.int32), a["rgb"].view(np.int32)), "tile shards do not compose"
+        assert rays == a["stats"].rays and a["stats"].bvh_stack_overflows == 0
+    orc = Oracle(fs)
+    for (x, y) in _blocks(W, H, 3, 2):
+        ref = orc.render_region(W, H, x, y, 8, 8, mode=_abi.HIPEXEC_MODE_CPU, max_depth=depth, tone=1, n_threads=8)
+        assert np.array_equal(a["ids"][y:y + 8, x:x + 8], ref["ids"]), f"hit ids differ in block {(x, y)}"
+        assert_image_parity(a["rgb"][y:y + 8, x:x + 8], ref["rgb"], min_frac=1.0)
+
+
 def test_c5_many_lights_4k_strip():
     """Benchmark config 5 (16 lamps, 16 spheres, 20k triangles) at 3840x2160: one 8-row tile in
     every 9 is rendered (30 tiles), oracle-checked on a grid of blocks inside those tiles."""
