@@ -556,6 +556,20 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
     return st.found != 0u;
 }
 
+// Workgroups are handed to the 8 XCDs in turn (workgroup b runs on XCD b mod 8), each XCD with an L2 of its own.
+// Runs of XCD_RUN consecutive work items go to one XCD, the runs to the XCDs in turn: neighbouring tiles share an L2
+// and the XCDs still get the same mix of cheap and expensive parts of the image.
+#ifndef XCD_RUN
+#define XCD_RUN 16u
+#endif
+DEV uint32_t xcd_block() {
+    const uint32_t b = blockIdx.x, g = gridDim.x;
+    const uint32_t full = g / (8u * XCD_RUN) * (8u * XCD_RUN);          // the ragged end keeps the plain order
+    if (b >= full) return b;
+    const uint32_t xcd = b & 7u, idx = b >> 3;                            // idx-th workgroup of this XCD
+    return ((idx / XCD_RUN) * 8u + xcd) * XCD_RUN + idx % XCD_RUN;
+}
+
 // lanes with `want` get consecutive indices from the LDS counter *next (one LDS atomic per wave);
 // returns the first index past the ones handed out to this wave
 DEV uint32_t wave_take(bool want, uint32_t *next, uint32_t &idx) {
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ uint32_t next;
     const uint32_t per_block = (uint32_t)refill_below >> 16;          // rays owned by a block
-    const uint32_t base = blockIdx.x * per_block;
+    const uint32_t base = xcd_block() * per_block;
     const uint32_t end = min(n, base + per_block);
     if (threadIdx.x == 0) next = base;
     __syncthreads();
@@ -701,7 +715,7 @@ __global__ __launch_bounds__(256) void k_bvh_closest_pk(DScene S, DBvh B, const 
                                                         int klass)
 {
     __shared__ uint32_t pstack[4][3 * PK_STACK];
-    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    uint32_t j = xcd_block() * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
     load_ray(rays, valid ? j : 0u, o, d, s, aux);
@@ -769,7 +783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     __shared__ uint16_t list[SH_LAMPS * 256];
     __shared__ uint32_t wcnt[SH_LAMPS * 4 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    uint32_t j = blockIdx.x * per_block + tid;
+    uint32_t j = xcd_block() * per_block + tid;
     bool valid = tid < per_block && j < n;
     f3 o, d; uint32_t s, aux;
     load_ray(rays, valid ? j : 0u, o, d, s, aux);
