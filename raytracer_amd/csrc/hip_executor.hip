@@ -474,8 +474,9 @@ int call_begin(hipexec *h, bool timing, uint32_t flags)
     bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
     h->use_bvh = want_bvh && h->bvh_ok;
     h->S.bilinear = (flags & HIPEXEC_FLAG_BILINEAR) ? 1u : 0u;
-    if (h->call_open) {   // a previous asynchronous call has not been collected yet
+    if (h->call_open) {   // a previous asynchronous call has not been collected yet (or failed half-way)
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->side) HIPCHK(hipStreamSynchronize(h->side));
     }
     h->timing = timing;
     memset(&h->acc, 0, sizeof h->acc);
