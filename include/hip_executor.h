@@ -9,6 +9,11 @@
  * failure and never throws; hipexec_last_error() returns the message for the calling
  * thread's last failure.
  *
+ * Threads: different executors may be used from different threads at the same time; the calls
+ * on one executor must not overlap (the reference's executor is used the same way, one render
+ * call at a time, ray_tracer_cl.cpp:14-55).  An executor may start host threads and streams of
+ * its own for a call; they are idle between calls and end with hipexec_destroy().
+ *
  * Arithmetic contract: all tracing arithmetic is IEEE-754 binary32, evaluated in the
  * reference's source order with no FMA contraction, correctly rounded divide and sqrt.
  * Two rule sets exist because the reference's two back ends disagree:
