@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
 
-// camera rays of the pixel grid into ray records; sample s = r * n_slots + slot.  Slots
+// camera rays of the pixel grid into ray records; sample s = sample_index(slot, r).  Slots
 // outside the frame get aux = 1 and a hit record with id -2, and are skipped by k_bvh_closest.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_raygen(DScene S, Frame F, float4 *__restrict__ rays, float4 *__restrict__ hits)
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_raygen(DScene S, Frame F, float4 *__res
     f3 o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
 #pragma unroll
     for (int r = 0; r < SPP; r++) {
-        uint32_t s = (uint32_t)r * F.n_slots + slot;
+        uint32_t s = sample_index<SPP>(F, slot, r);
         store_ray(rays, s, o, d[r], s, active ? 0u : 1u);
         if (!active) hits[s] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
     }
