@@ -170,6 +170,7 @@ struct hipexec {
     // side stream of this lane: lights a level (shadow rays, shading) while the next level is traced on `stream`
     hipStream_t side = nullptr;
     hipEvent_t ev_hits[2] = {nullptr, nullptr}, ev_lit[2] = {nullptr, nullptr};
+    bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
@@ -681,7 +682,7 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
         if (S.n_lamp) {
             const uint32_t per_block = small_launch_share(n, 256u);
             LAUNCH_ON(side_s, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
-                      h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block);
+                      h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr);
         }
         LAUNCH_ON(side_s, HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
                   h->lamp_words, h->local.as<float4>() + (size_t)level * stride, spawn, (float4 *)nullptr, (uint32_t *)nullptr);
@@ -729,7 +730,7 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
         if (S.n_lamp && h->use_bvh) {
             const uint32_t per_block = small_launch_share(n, 256u);
             LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
-                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block);
+                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr);
         } else if (S.n_lamp) {
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
                    h->shadowq.as<float4>(), h->d_cnt32 + 1);
@@ -939,6 +940,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (const char *e = getenv("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
     h->n_cnt32 = std::max(8u, n_lamp + 1u);

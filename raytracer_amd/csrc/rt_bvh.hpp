@@ -325,6 +325,43 @@ DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
     if (b.id < 0 || t < b.t || (t == b.t && id < b.id)) { b.t = t; b.u = u; b.v = v; b.id = id; }
 }
 
+// One inner-node step of a lane: the four slot boxes of record N against the ray, the nearest hit slot
+// becomes the lane's node, the others go on its stack (farthest first).
+template <bool UNIFORM>
+DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__ N, float limit, uint32_t *stk, uint32_t &node, int &sp,
+                        uint32_t &overflow)
+{
+    if (UNIFORM) asm volatile("; wave-uniform record" ::: );          // keeps the two instances apart (scalar vs vector fetch)
+    float4 lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { lo[k] = N[k]; hi[k] = N[4 + k]; }
+    float4 cone = N[8];
+    float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
+    float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
+    float tk[4]; bool hk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
+    // hit slots in order of entry: the nearest is visited next, the others go on the stack, farthest first
+    float key[4]; uint32_t ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { key[k] = hk[k] ? fminf(tk[k], 3.0e38f) : __builtin_inff(); ref[k] = hk[k] ? __float_as_uint(hi[k].w) : BVH_NONE; }
+#define BVH_CSWAP(a, b) { bool sw = key[b] < key[a]; float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
+              uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; }
+    BVH_CSWAP(0, 1) BVH_CSWAP(2, 3) BVH_CSWAP(0, 2) BVH_CSWAP(1, 3) BVH_CSWAP(1, 2)
+#undef BVH_CSWAP
+#pragma unroll
+    for (int k = 3; k >= 1; k--) {
+        if (ref[k] != BVH_NONE) {
+            if (sp < B.stack_limit) { stk[256 * sp] = ref[k]; sp++; }
+            else overflow = 1u;
+        }
+    }
+    if (overflow) node = BVH_NONE;
+    else if (ref[0] != BVH_NONE) node = ref[0];
+    else if (sp > 0) { sp--; node = stk[256 * sp]; }
+    else node = BVH_NONE;
+}
+
 // ---------------------------------------------------------------------------------------
 // Burst form of the traversal for kernels that refill idle lanes: the lanes of a wave whose
 // `node` is not BVH_NONE advance until fewer than `min_active` of them are left, so that the
@@ -342,7 +379,7 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
 // inner nodes until no lane has one, then leaves.)
 template <int MODE, bool ANY>
 DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &best, uint32_t *stk, int min_active,
-                   uint32_t &n_nodes, uint32_t &n_tris, int sched = 8)
+                   uint32_t &n_nodes, uint32_t &n_tris, int sched = 8, const float4 *__restrict__ nodes_sc = nullptr)
 {
     const float4 *__restrict__ T = B.tris;
     uint32_t node = st.node;
@@ -356,37 +393,20 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
         if (n_inner + n_leaf == 0 || n_inner + n_leaf < min_active) break;
         const bool inner_step = sched ? (n_inner * 8 >= n_leaf * sched) : (n_inner > 0);
         if (inner_step) {
-            if (at_inner) {
+            // Neighbouring rays mostly sit on the same node near the top of the tree: if every lane of this step does, the
+            // record comes through the scalar cache (one fetch per wave) and the texture-address units are left to the
+            // steps whose lanes have spread out.
+            const unsigned long long m_inner = __ballot(at_inner);
+            const uint32_t lead_node = (uint32_t)__shfl((int)node, __ffsll((long long)m_inner) - 1);
+            // (nodes_sc: the node array as a restrict-qualified kernel argument; only then can the compiler prove that
+            // the kernel's own stores do not touch it and use scalar loads)
+            const bool uniform = nodes_sc != nullptr && __ballot(at_inner && node == lead_node) == m_inner;
+            if (uniform) {
+                const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)lead_node);
+                if (at_inner) { n_nodes++; bvh_inner_step<true>(B, r, nodes_sc + 9 * (size_t)un, limit, stk, node, sp, overflow); }
+            } else if (at_inner) {
                 n_nodes++;
-                const float4 *N = B.nodes + 9 * (size_t)node;
-                float4 lo[4], hi[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { lo[k] = N[k]; hi[k] = N[4 + k]; }
-                float4 cone = N[8];
-                float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
-                float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
-                float tk[4]; bool hk[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
-                // hit slots in order of entry: the nearest is visited next, the others go on the stack, farthest first
-                float key[4]; uint32_t ref[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { key[k] = hk[k] ? fminf(tk[k], 3.0e38f) : __builtin_inff(); ref[k] = hk[k] ? __float_as_uint(hi[k].w) : BVH_NONE; }
-#define BVH_CSWAP(a, b) { bool sw = key[b] < key[a]; float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
-                          uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; }
-                BVH_CSWAP(0, 1) BVH_CSWAP(2, 3) BVH_CSWAP(0, 2) BVH_CSWAP(1, 3) BVH_CSWAP(1, 2)
-#undef BVH_CSWAP
-#pragma unroll
-                for (int k = 3; k >= 1; k--) {
-                    if (ref[k] != BVH_NONE) {
-                        if (sp < B.stack_limit) { stk[256 * sp] = ref[k]; sp++; }
-                        else overflow = 1u;
-                    }
-                }
-                if (overflow) node = BVH_NONE;
-                else if (ref[0] != BVH_NONE) node = ref[0];
-                else if (sp > 0) { sp--; node = stk[256 * sp]; }
-                else node = BVH_NONE;
+                bvh_inner_step<false>(B, r, B.nodes + 9 * (size_t)node, limit, stk, node, sp, overflow);
             }
         } else if (at_leaf) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
@@ -545,10 +565,10 @@ DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float 
 // is hit.  `stk` points at this lane's column of the LDS stack (entries 256 words apart).
 template <int MODE, bool ANY>
 DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Best &best, uint32_t *stk,
-                      uint32_t &n_nodes, uint32_t &n_tris)
+                      uint32_t &n_nodes, uint32_t &n_tris, const float4 *__restrict__ nodes_sc = nullptr)
 {
     TState st; st.node = B.root; st.sp = 0; st.limit = limit; st.found = 0u; st.overflow = 0u;
-    bvh_burst<MODE, ANY>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris);
+    bvh_burst<MODE, ANY>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, 8, nodes_sc);
     if (st.overflow) {
         n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
         st.found = bvh_linear<MODE, ANY>(B, o, d, best, n_tris) ? 1u : 0u;
@@ -775,7 +795,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
                                                     uint32_t *__restrict__ occl, uint32_t lw,
-                                                    unsigned long long *__restrict__ counters, uint32_t per_block)
+                                                    unsigned long long *__restrict__ counters, uint32_t per_block,
+                                                    const float4 *__restrict__ nodes_sc)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ float Px[256], Py[256], Pz[256];
@@ -849,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                 if (!occluded) {
                     TRay r = tray_make(S, B, P, toLamp);
                     Best none = best_none();
-                    occluded = bvh_traverse<MODE, true>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris);
+                    occluded = bvh_traverse<MODE, true>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris, nodes_sc);
                 }
                 if (occluded) atomicOr(&occl[(size_t)sample_of[t2] * lw + (l >> 5)], 1u << (l & 31u));
                 n_rays++;
