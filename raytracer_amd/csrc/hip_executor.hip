@@ -170,6 +170,7 @@ struct hipexec {
     // side stream of this lane: lights a level (shadow rays, shading) while the next level is traced on `stream`
     hipStream_t side = nullptr;
     hipEvent_t ev_hits[2] = {nullptr, nullptr}, ev_lit[2] = {nullptr, nullptr};
+    int fuse_shade = 1;                       // HIPEXEC_FUSE_SHADE: 0 k_shade always a launch of its own, 1 by batch, 2 always fused
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
@@ -637,6 +638,16 @@ int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
 
 constexpr uint32_t OVERLAP_MAX_SAMPLES = 2500000u;
 
+// Shading inside k_bvh_shadow (the occlusion bits of a block stay in LDS): needs them to fit one word per sample.
+// Measured: worth 2-6 % of a whole frame with few lamps (C2, C3, C4); with 16 lamps the shading loop in the same kernel
+// costs the traversal registers (C5 +1 %), and on the side stream of a small batch a separate k_shade overlaps better
+// (1/8 of C2 +5 %), so those keep the two launches.
+bool fused_shading(const hipexec *h, bool side_stream)
+{
+    if (h->lamp_words != 1 || h->fuse_shade == 0) return false;
+    return h->fuse_shade == 2 || (!side_stream && h->S.n_lamp <= 8);
+}
+
 // k_bvh_tail takes over when the queue of a level is small and at least two levels remain (for the last
 // level alone the separate, coherent kernels are as good).
 bool use_tail(const hipexec *h, uint32_t n_rays, int level, int depth)
@@ -679,13 +690,20 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
                       h->d_cnt32);
         }
         HIPCHK(hipStreamWaitEvent(side_s, h->ev_hits[level & 1], 0));
-        if (S.n_lamp) {
-            const uint32_t per_block = small_launch_share(n, 256u);
-            LAUNCH_ON(side_s, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
-                      h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr);
+        const uint32_t per_block = small_launch_share(n, 256u);
+        float4 *local_level = h->local.as<float4>() + (size_t)level * stride;
+        if (fused_shading(h, true)) {
+            LAUNCH_ON(side_s, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, true>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits,
+                      n, h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr,
+                      local_level, (int)spawn, (float4 *)nullptr, (uint32_t *)nullptr);
+        } else {
+            if (S.n_lamp)
+                LAUNCH_ON(side_s, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, false>), (n + per_block - 1) / per_block, S, h->B, cur_rays,
+                          cur_hits, n, h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block,
+                          h->uniform_fetch ? h->B.nodes : nullptr, (float4 *)nullptr, 0, (float4 *)nullptr, (uint32_t *)nullptr);
+            LAUNCH_ON(side_s, HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
+                      h->lamp_words, local_level, spawn, (float4 *)nullptr, (uint32_t *)nullptr);
         }
-        LAUNCH_ON(side_s, HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
-                  h->lamp_words, h->local.as<float4>() + (size_t)level * stride, spawn, (float4 *)nullptr, (uint32_t *)nullptr);
         HIPCHK(hipEventRecord(h->ev_lit[level & 1], side_s));
         if (!spawn) break;
         uint32_t nn = 0;
@@ -727,10 +745,20 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
     int level = 0;
     for (;; level++) {
         HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
-        if (S.n_lamp && h->use_bvh) {
+        const bool spawn = level < depth;
+        float4 *local_level = h->local.as<float4>() + (size_t)level * stride;
+        bool shaded = false;
+        if (h->use_bvh && fused_shading(h, false)) {
             const uint32_t per_block = small_launch_share(n, 256u);
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
-                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr);
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, true>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
+                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr,
+                   local_level, (int)spawn, next_rays, h->d_cnt32);
+            shaded = true;
+        } else if (S.n_lamp && h->use_bvh) {
+            const uint32_t per_block = small_launch_share(n, 256u);
+            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, false>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
+                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr,
+                   (float4 *)nullptr, 0, (float4 *)nullptr, (uint32_t *)nullptr);
         } else if (S.n_lamp) {
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
                    h->shadowq.as<float4>(), h->d_cnt32 + 1);
@@ -743,9 +771,9 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
                                                       h->occl.as<uint32_t>(), h->lamp_words));
             }
         }
-        bool spawn = level < depth;
-        LAUNCH(HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
-               h->lamp_words, h->local.as<float4>() + (size_t)level * stride, spawn, next_rays, h->d_cnt32);
+        if (!shaded)
+            LAUNCH(HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
+                   h->lamp_words, local_level, spawn, next_rays, h->d_cnt32);
         if (!spawn) break;
         uint32_t nn = 0;
         CHK(read_count(h, 0, &nn));
@@ -940,6 +968,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (const char *e = getenv("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));

@@ -791,13 +791,15 @@ __global__ __launch_bounds__(256) void k_bvh_anyhit(DScene S, DBvh B, const floa
 // ---------------------------------------------------------------------------------------
 constexpr int SH_LAMPS = 4;
 
-template <int MODE>
+template <int MODE, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
                                                     uint32_t *__restrict__ occl, uint32_t lw,
                                                     unsigned long long *__restrict__ counters, uint32_t per_block,
-                                                    const float4 *__restrict__ nodes_sc)
+                                                    const float4 *__restrict__ nodes_sc, float4 *__restrict__ local, int spawn,
+                                                    float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
 {
+    __shared__ uint32_t occ_lds[FUSED ? 256 : 1];          // FUSED (at most 32 lamps): the block's occlusion bits stay here
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ float Px[256], Py[256], Pz[256];
     __shared__ uint32_t sample_of[256];
@@ -815,6 +817,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     else { sf.P = mk(0.f, 0.f, 0.f); sf.N = mk(0.f, 0.f, 1.f); }
     Px[tid] = sf.P.x; Py[tid] = sf.P.y; Pz[tid] = sf.P.z;
     sample_of[tid] = s;
+    if (FUSED) occ_lds[tid] = 0u;
     const float dotWithDir = dot(d, sf.N);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
     for (uint32_t l0 = 0; l0 < S.n_lamp; l0 += SH_LAMPS) {
@@ -872,11 +875,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                     Best none = best_none();
                     occluded = bvh_traverse<MODE, true>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris, nodes_sc);
                 }
-                if (occluded) atomicOr(&occl[(size_t)sample_of[t2] * lw + (l >> 5)], 1u << (l & 31u));
+                if (occluded) {
+                    if (FUSED) atomicOr(&occ_lds[t2], 1u << l);
+                    else atomicOr(&occl[(size_t)sample_of[t2] * lw + (l >> 5)], 1u << (l & 31u));
+                }
                 n_rays++;
             }
         }
         __syncthreads();
+    }
+    if (FUSED) {
+        // shading of the block's samples right here: the occlusion bits never leave LDS and k_shade's launch is saved
+        // (ray and hit are read again rather than kept in registers through the traversal)
+        bool bounce = false;
+        f3 bo = mk(0.f, 0.f, 0.f), bd = mk(0.f, 0.f, 1.f);
+        if (valid) {
+            load_ray(rays, j, o, d, s, aux);
+            float4 hh = hits[j];
+            if (__float_as_int(hh.w) >= -1)
+                local[s] = shade_sample<MODE>(S, o, d, hh, &occ_lds[tid], spawn != 0, bounce, bo, bd);
+        }
+        if (spawn && next_rays) {
+            __shared__ uint32_t append_scratch[5];
+            uint32_t pos = block_append(bounce, next_count, append_scratch);
+            if (bounce) store_ray(next_rays, pos, bo, bd, s, 0u);
+        }
     }
     bvh_count(counters, 2, n_nodes, n_tris, n_rays);
 }

@@ -849,8 +849,41 @@ __global__ __launch_bounds__(256) void k_shadowgen(DScene S, const float4 *__res
 }
 
 // ---------------------------------------------------------------------------------------
-// k_shade: one thread per ray of the current level.  Writes local[s] = {colour, w} where
-// w = reflectionFactor if the sample continues with a bounce ray and -1 otherwise, clears the
+// Colour of one sample of a level: {colour, w} with w = reflectionFactor if the sample continues
+// with a bounce ray (returned in bo, bd) and -1 otherwise (ray_tracer.cpp:165-199 /
+// ray_tracer_cl.cpp:119-174).  `occ` points at the sample's occlusion words (bit l: lamp l is hidden).
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *occ, bool spawn, bool &bounce, f3 &bo, f3 &bd)
+{
+    f3 ret; float w = -1.0f;
+    if (__float_as_int(h.w) < 0) {
+        // miss: ray_tracer.cpp:199 returns the horizon; ray_tracer_cl.cpp:119-123 adds it to 0
+        f3 hz = mk(S.horizon[0], S.horizon[1], S.horizon[2]);
+        ret = (MODE == HIPEXEC_MODE_CL) ? (mk(0.f, 0.f, 0.f) + hz) : hz;
+    } else {
+        Surf sf = surface(S, o, d, h, true);
+        ret = (MODE == HIPEXEC_MODE_CL) ? mk(0.f, 0.f, 0.f) : mk(S.ambient[0], S.ambient[1], S.ambient[2]);
+        for (uint32_t l = 0; l < S.n_lamp; l++) {
+            float4 lp = S.lamp[l];
+            f3 toLamp = xyz(lp) - sf.P;
+            float dotWithLamp = dot(toLamp, sf.N);
+            float dotWithDir = dot(d, sf.N);
+            if (!casts_shadow_ray<MODE>(dotWithDir, dotWithLamp)) continue;
+            if (occ[l >> 5] & (1u << (l & 31u))) continue;
+            ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
+        }
+        if (MODE == HIPEXEC_MODE_CPU && spawn && sf.kr > RT_EPSF) {
+            bounce = true; w = sf.kr;
+            bo = sf.P;
+            bd = d - 2.0f * sf.N * dot(d, sf.N);
+        }
+    }
+    return make_float4(ret.x, ret.y, ret.z, w);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_shade: one thread per ray of the current level.  Writes local[s] = shade_sample(...), clears the
 // occlusion bits of s, and appends the bounce ray (ray_tracer.cpp:190-196) to next_rays unless
 // next_rays is null (then k_bounce has queued the bounce rays of this level already).
 // ---------------------------------------------------------------------------------------
@@ -865,34 +898,10 @@ __global__ __launch_bounds__(256) void k_shade(DScene S, const float4 *__restric
     f3 o, d; uint32_t s, aux;
     load_ray(rays, valid ? j : 0u, o, d, s, aux);
     float4 h = hits[valid ? j : 0u];
-    int id = __float_as_int(h.w);
     bool bounce = false;
     f3 bo = mk(0.f, 0.f, 0.f), bd = mk(0.f, 0.f, 1.f);
-    if (valid && id >= -1) {
-        f3 ret; float w = -1.0f;
-        if (id < 0) {
-            // miss: ray_tracer.cpp:199 returns the horizon; ray_tracer_cl.cpp:119-123 adds it to 0
-            f3 hz = mk(S.horizon[0], S.horizon[1], S.horizon[2]);
-            ret = (MODE == HIPEXEC_MODE_CL) ? (mk(0.f, 0.f, 0.f) + hz) : hz;
-        } else {
-            Surf sf = surface(S, o, d, h, true);
-            ret = (MODE == HIPEXEC_MODE_CL) ? mk(0.f, 0.f, 0.f) : mk(S.ambient[0], S.ambient[1], S.ambient[2]);
-            for (uint32_t l = 0; l < S.n_lamp; l++) {
-                float4 lp = S.lamp[l];
-                f3 toLamp = xyz(lp) - sf.P;
-                float dotWithLamp = dot(toLamp, sf.N);
-                float dotWithDir = dot(d, sf.N);
-                if (!casts_shadow_ray<MODE>(dotWithDir, dotWithLamp)) continue;
-                if (occl[(size_t)s * lw + (l >> 5)] & (1u << (l & 31u))) continue;
-                ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
-            }
-            if (MODE == HIPEXEC_MODE_CPU && spawn && sf.kr > RT_EPSF) {
-                bounce = true; w = sf.kr;
-                bo = sf.P;
-                bd = d - 2.0f * sf.N * dot(d, sf.N);
-            }
-        }
-        local[s] = make_float4(ret.x, ret.y, ret.z, w);
+    if (valid && __float_as_int(h.w) >= -1) {
+        local[s] = shade_sample<MODE>(S, o, d, h, occl + (size_t)s * lw, spawn, bounce, bo, bd);
         for (uint32_t k = 0; k < lw; k++) occl[(size_t)s * lw + k] = 0u;
     }
     if (spawn && next_rays) {

@@ -183,17 +183,20 @@ def test_camera_rays_as_packets_or_per_lane(packet, backends, monkeypatch):
                 assert np.array_equal(got["rgb"].view(np.int32), base["rgb"].view(np.int32))
 
 
+@pytest.mark.parametrize("fuse", ["0", "2"])
 @pytest.mark.parametrize("tail_max", ["0", "300000"])
 @pytest.mark.parametrize("overlap", ["0", "2"])
-def test_levels_on_one_or_two_streams(overlap, tail_max, monkeypatch):
+def test_levels_on_one_or_two_streams(overlap, tail_max, fuse, monkeypatch):
     """HIPEXEC_OVERLAP=2 lights every level on a side stream while the next one is traced, 0 keeps one
     stream per lane; HIPEXEC_TAIL_MAX=0 traces every level with its own launches, otherwise small ray
-    queues are followed to the end of their paths by one kernel.  The frame, the hit ids and the ray
-    counts are those of the oracle in every combination."""
+    queues are followed to the end of their paths by one kernel; HIPEXEC_FUSE_SHADE=2 shades inside the
+    shadow-ray kernel, 0 in a launch of its own.  The frame, the hit ids and the ray counts are those of the
+    oracle in every combination."""
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
     monkeypatch.setenv("HIPEXEC_OVERLAP", overlap)
     monkeypatch.setenv("HIPEXEC_TAIL_MAX", tail_max)
+    monkeypatch.setenv("HIPEXEC_FUSE_SHADE", fuse)
     fs = scenegen.small_variant("mirror").to_flat()
     W, H = 48, 132
     orc = Oracle(fs)
