@@ -112,6 +112,11 @@ typedef struct hipexec_render_cfg {
 } hipexec_render_cfg;
 
 #define HIPEXEC_FLAG_TIME_KERNELS 1   /* time every kernel with HIP events (fills *_ms in stats) */
+/* With HIPEXEC_FLAG_TIME_KERNELS: time only the kernel classes k whose bit HIPEXEC_FLAG_TIME_CLASS(k) is set (none
+ * set: all classes).  Every timed launch costs two event records on its stream; a measurement of one class leaves the
+ * others undisturbed. */
+#define HIPEXEC_FLAG_TIME_CLASS_SHIFT 8
+#define HIPEXEC_FLAG_TIME_CLASS(k) (1 << (HIPEXEC_FLAG_TIME_CLASS_SHIFT + (k)))
 #define HIPEXEC_FLAG_SCAN         2   /* this call: index-order scans like the reference's loops
                                          (the only algorithm that reports tests_*_any)           */
 #define HIPEXEC_FLAG_BVH          4   /* this call: bounding volume hierarchy (the default unless

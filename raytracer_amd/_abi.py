@@ -10,6 +10,7 @@ HIPEXEC_MODE_CPU = 0
 HIPEXEC_MODE_CL = 1
 HIPEXEC_TILE_ROWS = 8
 HIPEXEC_FLAG_TIME_KERNELS = 1
+HIPEXEC_FLAG_TIME_CLASS_SHIFT = 8
 HIPEXEC_FLAG_SCAN = 2
 HIPEXEC_FLAG_BVH = 4
 HIPEXEC_FLAG_BILINEAR = 8

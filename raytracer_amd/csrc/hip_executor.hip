@@ -152,7 +152,8 @@ struct hipexec {
     unsigned long long *h_cnt64 = nullptr;    // pinned
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
-    bool timing = false;
+    uint32_t timing = 0;                      // bit k: launches of kernel class k are bracketed by HIP events
+    bool timed_this = false;                  // the launch between timed_begin and timed_end is being timed
     hipexec_stats *pending_stats = nullptr;
     hipexec_stats acc{};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -443,7 +444,8 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
 int timed_begin(hipexec *h, int klass, hipStream_t stream)
 {
     h->acc.launches[klass]++;
-    if (!h->timing) return HIPEXEC_OK;
+    h->timed_this = ((h->timing >> klass) & 1u) != 0u;
+    if (!h->timed_this) return HIPEXEC_OK;
     TimedLaunch t; t.klass = klass;
     for (hipEvent_t *e : {&t.a, &t.b}) {
         if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
@@ -456,7 +458,7 @@ int timed_begin(hipexec *h, int klass, hipStream_t stream)
 int timed_end(hipexec *h, hipStream_t stream)
 {
     HIPCHK(hipGetLastError());
-    if (!h->timing) return HIPEXEC_OK;
+    if (!h->timed_this) return HIPEXEC_OK;
     HIPCHK(hipEventRecord(h->timed.back().b, stream));
     return HIPEXEC_OK;
 }
@@ -468,9 +470,17 @@ int timed_end(hipexec *h, hipStream_t stream)
     } while (0)
 #define LAUNCH(klass, kernel, grid, ...) LAUNCH_ON(h->stream, klass, kernel, grid, __VA_ARGS__)
 
+// kernel classes to time: none without HIPEXEC_FLAG_TIME_KERNELS, else those named by HIPEXEC_FLAG_TIME_CLASS (all if none is named)
+inline uint32_t timing_mask(int32_t flags)
+{
+    if (!(flags & HIPEXEC_FLAG_TIME_KERNELS)) return 0u;
+    uint32_t m = ((uint32_t)flags >> HIPEXEC_FLAG_TIME_CLASS_SHIFT) & ((1u << HIPEXEC_K_COUNT) - 1u);
+    return m ? m : (1u << HIPEXEC_K_COUNT) - 1u;
+}
+
 inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
-int call_begin(hipexec *h, bool timing, uint32_t flags)
+int call_begin(hipexec *h, uint32_t timing, uint32_t flags)
 {
     HIPCHK(hipSetDevice(h->device));
     bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
@@ -882,7 +892,7 @@ int render_sub(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t 
     return render_tiles<HIPEXEC_MODE_CPU>(h, c, d_rgba, d_ids, sub, n_sub);
 }
 
-int call_begin(hipexec *h, bool timing, uint32_t flags);
+int call_begin(hipexec *h, uint32_t timing, uint32_t flags);
 
 int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
 {
@@ -1107,7 +1117,7 @@ int hipexec_render_device(hipexec_t *h, const hipexec_render_cfg *cfg, float *d_
     if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
     CHK(validate_cfg(cfg));
     if (!d_out_rgba) return fail(HIPEXEC_E_INVALID, "d_out_rgba is NULL");
-    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
+    CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
     int rc = render_dispatch(h, cfg, reinterpret_cast<float4 *>(d_out_rgba), d_out_ids);
     if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
@@ -1127,7 +1137,7 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg, float *out_rgb, 
     HIPCHK(hipSetDevice(h->device));
     CHK(h->out_rgba.reserve(rows * W * 16));
     if (out_ids) CHK(h->out_ids.reserve(rows * W * 4 * spp));
-    CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
+    CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
     int rc = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
     if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
     if (cfg->tile_first == 0 && cfg->tile_step == 1) {
@@ -1181,7 +1191,7 @@ int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int3
     for (int t0 = 0; t0 < n_tiles && rc == HIPEXEC_OK; t0 += tiles_per_step) {
         rc = [&]() -> int {
             h->win_lo = t0; h->win_hi = std::min(n_tiles, t0 + tiles_per_step);
-            CHK(call_begin(h, (cfg->flags & HIPEXEC_FLAG_TIME_KERNELS) != 0, cfg->flags));
+            CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
             int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), nullptr);
             if (r != HIPEXEC_OK) { h->call_open = false; return r; }
             const int y0 = t0 * HIPEXEC_TILE_ROWS, rows = std::min(cfg->height, h->win_hi * HIPEXEC_TILE_ROWS) - y0;

@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // counters[16] += bounce rays generated here (levels above level0).
 // ---------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bvh_tail(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n, int level0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_tail(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n, int level0,
                                                   int depth, float4 *__restrict__ local, size_t level_stride,
                                                   unsigned long long *__restrict__ counters)
 {

@@ -69,7 +69,14 @@ class HipExecutor:
     # -- frame ----------------------------------------------------------------------------
     @staticmethod
     def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo=None, bilinear=False):
-        flags = _abi.HIPEXEC_FLAG_TIME_KERNELS if time_kernels else 0
+        # time_kernels: False / True (every kernel class) / an iterable of class indices (only those classes)
+        flags = 0
+        if time_kernels is True:
+            flags = _abi.HIPEXEC_FLAG_TIME_KERNELS
+        elif time_kernels:
+            flags = _abi.HIPEXEC_FLAG_TIME_KERNELS
+            for k in time_kernels:
+                flags |= 1 << (_abi.HIPEXEC_FLAG_TIME_CLASS_SHIFT + int(k))
         if bilinear:
             flags |= _abi.HIPEXEC_FLAG_BILINEAR
         if algo is not None:
