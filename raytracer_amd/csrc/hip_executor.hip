@@ -174,6 +174,7 @@ struct hipexec {
     int fuse_shade = 1;                       // HIPEXEC_FUSE_SHADE: 0 k_shade always a launch of its own, 1 by batch, 2 always fused
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
+    bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
 };
@@ -610,7 +611,8 @@ int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t 
 {
     if (h->packet && klass_count == 0) {
         // camera rays: the 64 rays of a wave are one 8x8-pixel tile of one sub-sample and walk the hierarchy as a packet
-        LAUNCH(klass_time, (k_bvh_closest_pk<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count);
+        LAUNCH(klass_time, (k_bvh_closest_pk<MODE, false>), blocks_for(n), h->S, h->B, const_cast<float4 *>(rays), n, hits, h->d_cnt64,
+               klass_count, Frame{});
     } else if (h->bvh_refill) {
         // camera rays arrive in coherent 8x8 tiles (one ray per lane is best), bounce rays vary widely in length
         uint32_t per_block = h->closest_per_block ? (uint32_t)h->closest_per_block
@@ -864,7 +866,11 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         uint64_t n0 = (uint64_t)F.n_slots * SPP;
         if (n0 > 0xfffffff0ull) return fail(HIPEXEC_E_LIMIT, "batch of %llu samples exceeds 32-bit indexing", (unsigned long long)n0);
         CHK(reserve_trace_buffers(h, n0, depth + 1));
-        if (h->use_bvh) {
+        if (h->use_bvh && h->packet && h->fuse_raygen) {
+            // the packet kernel makes, stores and walks the camera rays in one launch
+            LAUNCH(HIPEXEC_K_PRIMARY, (k_bvh_closest_pk<MODE, true>), blocks_for(n0), S, h->B, h->rayA.as<float4>(), (uint32_t)n0,
+                   h->hit0.as<float4>(), h->d_cnt64, 0, F);
+        } else if (h->use_bvh) {
             LAUNCH(HIPEXEC_K_PRIMARY, (k_raygen<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>());
             CHK(launch_bvh_closest<MODE>(h, HIPEXEC_K_PRIMARY, h->rayA.as<float4>(), (uint32_t)n0, h->hit0.as<float4>(), 0));
         } else {
@@ -978,6 +984,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (const char *e = getenv("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));

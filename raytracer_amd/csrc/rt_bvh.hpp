@@ -728,17 +728,41 @@ __global__ __launch_bounds__(256) void k_bvh_closest(DScene S, DBvh B, const flo
     bvh_count(counters, klass, n_nodes, n_tris, 0u);
 }
 
-// Closest hits of rays that arrive in coherent groups of 64 (camera rays: one 8x8-pixel tile per wave): packet walk.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bvh_closest_pk(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+// Closest hits of rays that arrive in coherent groups of 64 (camera rays: one 4x4-pixel quadrant with its sub-samples
+// per wave): packet walk.  GEN: the kernel makes the camera rays itself (thread j = sample j: what k_raygen would have
+// stored for it, from the same expressions, hence the same bits), stores them for the kernels that light and shade the
+// level, and walks them at once: one launch and one pass over the ray records less per frame.
+template <int MODE, bool GEN>
+__global__ __launch_bounds__(256) void k_bvh_closest_pk(DScene S, DBvh B, float4 *__restrict__ rays, uint32_t n,
                                                         float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
-                                                        int klass)
+                                                        int klass, Frame F)
 {
     __shared__ uint32_t pstack[4][3 * PK_STACK];
     uint32_t j = xcd_block() * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
-    load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    if (GEN) {
+        constexpr int SPP = (MODE == HIPEXEC_MODE_CL) ? 1 : 4;
+        // inverse of sample_index: sample j -> pixel slot and sub-sample
+        uint32_t slot = j; int r = 0;
+        if (SPP == 4) {
+            const uint32_t pix = j & 15u, quad = (j >> 6) & 3u, blk = j >> 8;
+            r = (int)((j >> 4) & 3u);
+            slot = blk * 64u + ((quad >> 1) * 4u + (pix >> 2)) * 8u + (quad & 1u) * 4u + (pix & 3u);
+        }
+        int x, y, lrow;
+        const bool active = slot_to_pixel(F, slot, x, y, lrow);
+        if (!active) { x = min(x, F.W - 1); y = min(y, F.H - 1); }
+        o = mk(S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]);
+        d = camera_ray<MODE>(S, F, x, y, r);
+        aux = active ? 0u : 1u;
+        if (valid) {
+            store_ray(rays, j, o, d, j, aux);
+            if (!active) hits[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
+        }
+    } else {
+        load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    }
     valid = valid && aux == 0u;
     uint32_t n_nodes = 0, n_tris = 0, found = 0;
     Best sb = spheres_closest<MODE>(S, o, d);

@@ -387,6 +387,27 @@ DEV void camera_rays(const DScene &S, const Frame &F, int x, int y, f3 *d) {
     }
 }
 
+// direction of sub-sample r of pixel (x, y) alone: the expressions of camera_rays for d[r]
+template <int MODE>
+DEV f3 camera_ray(const DScene &S, const Frame &F, int x, int y, int r) {
+    float camHeight = 0.5f;
+    float camWidth = (float)F.W * (camHeight / (float)F.H);
+    float camDist = 1.0f;
+    float dh = camHeight / (float)F.H;
+    float dw = camWidth / (float)F.W;
+    float rayX = -(camWidth / 2) + (float)x * dw;
+    float rayY = -(camHeight / 2) + (float)y * dh;
+    f3 world = vecmat(mk(rayX, rayY, -camDist), S.cam_mat);
+    if (MODE != HIPEXEC_MODE_CL) {
+        f3 wdx = vecmat(mk(dw / 2.0f, 0.0f, 0.0f), S.cam_mat);
+        f3 wdy = vecmat(mk(0.0f, dh / 2.0f, 0.0f), S.cam_mat);
+        if (r == 1) world = world + wdx;
+        else if (r == 2) world = world + wdy;
+        else if (r == 3) world = (world + wdx) + wdy;
+    }
+    return normalize(world);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_primary(DScene S, Frame F, float4 *__restrict__ rays, float4 *__restrict__ hits,
                                                  unsigned long long *__restrict__ counters)
