@@ -26,7 +26,7 @@ for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if "pmc_sq/" in f.replace("\\", "/") and r["Counter_Name"] == "SQ_WAVES":
             disp[k] += 1
-# kernel durations from the trace (same command line, 2 timed steps + 1 warm-up = 3 frames)
+# kernel durations from the trace (same command line: 1 warm-up + 1 probe + 2 timed frames)
 dur = collections.defaultdict(float); calls = collections.defaultdict(int)
 for f in glob.glob(f"{src}/trace/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
@@ -35,23 +35,27 @@ for f in glob.glob(f"{src}/trace/*/*kernel_trace.csv"):
             dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; calls[k] += 1
 out = {}
 N_SIMD = 1024
+# bench.py renders warm-up frames, one probe frame (every class timed) and the timed steps with the chosen algorithm:
+# --steps 2 --warmup 1 in the trace run, --steps 1 --warmup 0 in the PMC runs
+TRACE_FRAMES, PMC_FRAMES = 4.0, 2.0
 for k, c in tot.items():
     d = dict(c)
-    # PMC runs render ONE frame; trace run renders 3
-    ms_frame = dur[k] / 3.0 if k in dur else None
+    ms_frame = dur[k] / TRACE_FRAMES if k in dur else None
     gui = d.get("GRBM_GUI_ACTIVE", 0) / 8.0                 # summed over the 8 XCDs
-    m = {"counters": d, "ms_per_frame_from_trace": ms_frame, "launches_per_frame": calls[k] / 3.0 if k in calls else None}
+    m = {"counters": d, "counters_cover_frames": PMC_FRAMES, "ms_per_frame_from_trace": ms_frame,
+         "launches_per_frame": calls[k] / TRACE_FRAMES if k in calls else None}
     if gui:
-        m["clock_ghz"] = gui / (ms_frame * 1e6) if ms_frame else None
+        m["clock_ghz"] = gui / (ms_frame * PMC_FRAMES * 1e6) if ms_frame else None
         # one wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts quad-cycles)
         m["valu_utilisation"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
         m["occupancy_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0) * 4.0 / (gui * N_SIMD)
     if "FETCH_SIZE" in d:
         # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reads half of a wide coalesced stream on gfx950 (x2 upper bound)
-        m["hbm_read_bytes_low"] = d["FETCH_SIZE"] * 1024.0
-        m["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 2048.0
+        # (bytes per frame)
+        m["hbm_read_bytes_low"] = d["FETCH_SIZE"] * 1024.0 / PMC_FRAMES
+        m["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 2048.0 / PMC_FRAMES
     if "WRITE_SIZE" in d:
-        m["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024.0
+        m["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024.0 / PMC_FRAMES
     if d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0) > 0:
         m["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     out[k] = m
