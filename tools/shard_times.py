@@ -7,7 +7,8 @@ from raytracer_amd import scenegen, _abi
 from raytracer_amd.executor import HipExecutor
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 W, H, depth, fn = {"c2": (1920, 1080, 3, scenegen.scene_c2), "c3": (3840, 2160, 5, scenegen.scene_c2),
-                   "c5": (3840, 2160, 0, scenegen.scene_c5)}[wl]
+                   "c5": (3840, 2160, 0, scenegen.scene_c5), "c1": (640, 480, 0, scenegen.scene_c1),
+                   "c4": (1920, 1080, 0, scenegen.scene_c4)}[wl]
 ex = HipExecutor(fn().to_flat(), device=0)
 out = torch.zeros((((H + 7) // 8) * 8, W, 4), dtype=torch.float32, device="cuda")
 base = None
