@@ -11,6 +11,7 @@ HIPEXEC_MODE_CL = 1
 HIPEXEC_TILE_ROWS = 8
 HIPEXEC_FLAG_TIME_KERNELS = 1
 HIPEXEC_FLAG_TIME_CLASS_SHIFT = 8
+HIPEXEC_K_PRIMARY, HIPEXEC_K_CLOSEST, HIPEXEC_K_ANYHIT, HIPEXEC_K_SHADE = 0, 1, 2, 3
 HIPEXEC_FLAG_SCAN = 2
 HIPEXEC_FLAG_BVH = 4
 HIPEXEC_FLAG_BILINEAR = 8

@@ -183,6 +183,39 @@ def test_camera_rays_as_packets_or_per_lane(packet, backends, monkeypatch):
                 assert np.array_equal(got["rgb"].view(np.int32), base["rgb"].view(np.int32))
 
 
+def test_camera_rays_made_by_the_packet_kernel_or_by_a_launch_of_their_own(backends, monkeypatch):
+    """HIPEXEC_FUSE_RAYGEN=0 stores the camera rays with k_raygen before the packet kernel walks them; by default the
+    packet kernel makes them itself.  Same expressions, hence the same frame bit for bit (ragged sizes included)."""
+    from raytracer_amd.executor import HipExecutor
+    for name in ("c2", "mirror"):
+        fs = scenegen.small_variant(name).to_flat()
+        monkeypatch.setenv("HIPEXEC_FUSE_RAYGEN", "0")
+        ex = HipExecutor(fs, device=0)
+        monkeypatch.setenv("HIPEXEC_FUSE_RAYGEN", "1")
+        ex_default = HipExecutor(fs, device=0)
+        with ex, ex_default:
+            for mode, depth, W, H in ((CPU, 2, 61, 43), (CL, 0, 50, 33)):
+                got = ex.render(W, H, mode=mode, max_depth=depth, tone=False, algo="bvh")
+                base = ex_default.render(W, H, mode=mode, max_depth=depth, tone=False, algo="bvh")
+                assert np.array_equal(got["ids"], base["ids"])
+                assert np.array_equal(got["rgb"].view(np.int32), base["rgb"].view(np.int32))
+                assert got["stats"].rays == base["stats"].rays
+                assert got["stats"].launches[0] == base["stats"].launches[0] + 1      # k_raygen
+
+
+def test_timing_by_kernel_class(backends):
+    """HIPEXEC_FLAG_TIME_KERNELS times every launch; with HIPEXEC_FLAG_TIME_CLASS bits only the named classes."""
+    fs, ex, orc = backends("c2")
+    every = ex.render(64, 48, mode=CPU, max_depth=2, want_ids=False, time_kernels=True, algo="bvh")["stats"]
+    assert all(every.kernel_ms[k] > 0.0 for k in range(4))
+    only = ex.render(64, 48, mode=CPU, max_depth=2, want_ids=False, time_kernels=[_abi.HIPEXEC_K_ANYHIT], algo="bvh")["stats"]
+    assert only.kernel_ms[_abi.HIPEXEC_K_ANYHIT] > 0.0
+    assert all(only.kernel_ms[k] == 0.0 for k in range(4) if k != _abi.HIPEXEC_K_ANYHIT)
+    assert list(only.launches) == list(every.launches) and only.rays == every.rays
+    none = ex.render(64, 48, mode=CPU, max_depth=2, want_ids=False, algo="bvh")["stats"]
+    assert all(none.kernel_ms[k] == 0.0 for k in range(4))
+
+
 @pytest.mark.parametrize("fuse", ["0", "2"])
 @pytest.mark.parametrize("tail_max", ["0", "300000"])
 @pytest.mark.parametrize("overlap", ["0", "2"])
