@@ -327,7 +327,7 @@ DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
 
 // One inner-node step of a lane: the four slot boxes of record N against the ray, the nearest hit slot
 // becomes the lane's node, the others go on its stack (farthest first).
-template <bool UNIFORM>
+template <bool UNIFORM, bool SORT = true>
 DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__ N, float limit, uint32_t *stk, uint32_t &node, int &sp,
                         uint32_t &overflow)
 {
@@ -341,6 +341,26 @@ DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__
     float tk[4]; bool hk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
+    if (!SORT) {
+        // Any-hit rays: the answer does not depend on the order of the walk, and ordering the slots by entry distance
+        // (five compare-exchanges) costs more than it finds occluders sooner (measured: C5 -8 %, C2 -2.5 % without it).
+        // The first hit slot is entered next, the others go on the stack.
+        uint32_t nxt = BVH_NONE;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (hk[k]) {
+                const uint32_t ref = __float_as_uint(hi[k].w);
+                if (nxt == BVH_NONE) nxt = ref;
+                else if (sp < B.stack_limit) { stk[256 * sp] = ref; sp++; }
+                else overflow = 1u;
+            }
+        }
+        if (overflow) node = BVH_NONE;
+        else if (nxt != BVH_NONE) node = nxt;
+        else if (sp > 0) { sp--; node = stk[256 * sp]; }
+        else node = BVH_NONE;
+        return;
+    }
     // hit slots in order of entry: the nearest is visited next, the others go on the stack, farthest first
     float key[4]; uint32_t ref[4];
 #pragma unroll
@@ -403,10 +423,10 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             const bool uniform = nodes_sc != nullptr && __ballot(at_inner && node == lead_node) == m_inner;
             if (uniform) {
                 const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)lead_node);
-                if (at_inner) { n_nodes++; bvh_inner_step<true>(B, r, nodes_sc + 9 * (size_t)un, limit, stk, node, sp, overflow); }
+                if (at_inner) { n_nodes++; bvh_inner_step<true, !ANY>(B, r, nodes_sc + 9 * (size_t)un, limit, stk, node, sp, overflow); }
             } else if (at_inner) {
                 n_nodes++;
-                bvh_inner_step<false>(B, r, B.nodes + 9 * (size_t)node, limit, stk, node, sp, overflow);
+                bvh_inner_step<false, !ANY>(B, r, B.nodes + 9 * (size_t)node, limit, stk, node, sp, overflow);
             }
         } else if (at_leaf) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
