@@ -10,14 +10,24 @@ import os
 import shutil
 import sys
 
+def newest(pattern):
+    """One file per pass directory: gpurun merges each run's files into the local copy, so earlier runs' files stay."""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        top = f.split("/")[2]
+        if top not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[top]):
+            by_dir[top] = f
+    return list(by_dir.values())
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
+for f in newest(f"{src}/trace/*/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(int)
-for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
+for f in newest(f"{src}/pmc_*/*/*counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -28,7 +38,7 @@ for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
             disp[k] += 1
 # kernel durations from the trace (same command line: 1 warm-up + 1 probe + 2 timed frames)
 dur = collections.defaultdict(float); calls = collections.defaultdict(int)
-for f in glob.glob(f"{src}/trace/*/*kernel_trace.csv"):
+for f in newest(f"{src}/trace/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if "rt::k_" in k:
