@@ -175,6 +175,8 @@ struct hipexec {
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
+    bool shadow_direct = true;                // HIPEXEC_SHADOW_DIRECT=0: shadow rays through the block's list in LDS (k_bvh_shadow)
+    uint32_t shadow_per_block = 256u;         // HIPEXEC_SHADOW_PER_BLOCK: samples owned by a block of k_bvh_shadow (multiple of 64, <= 256)
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
 };
@@ -675,6 +677,26 @@ int launch_tail(hipexec *h, const float4 *rays, uint32_t n, int level, int depth
     return HIPEXEC_OK;
 }
 
+// Shadow rays of a level (FUSED: and its shading) on `stream`.  Two forms of the kernel: the direct one (a lane keeps its
+// sample and goes through the lamps) and the one that compacts the block's (sample, lamp) pairs into a list in LDS first.
+// Measured on whole frames: equal on C2, C3 and C4, the direct form 9 % faster on C5 (16 lamps: four rounds of
+// compaction with their barriers); HIPEXEC_SHADOW_DIRECT=0 selects the list form.
+template <int MODE, bool FUSED>
+int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const float4 *hits, uint32_t n, float4 *local_level, bool spawn,
+                      float4 *next_rays, uint32_t *next_count)
+{
+    const uint32_t per_block = small_launch_share(n, h->shadow_per_block);
+    const uint32_t blocks = (n + per_block - 1) / per_block;
+    const float4 *nodes_sc = h->uniform_fetch ? h->B.nodes : nullptr;
+    if (h->shadow_direct)
+        LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
+                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count);
+    else
+        LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
+                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count);
+    return HIPEXEC_OK;
+}
+
 // trace_levels for the hierarchy with reflections, on two streams.  The bounce rays of a level depend
 // only on its hits, so k_bounce queues them at once and the main stream goes on to trace the next
 // level, while the side stream casts this level's shadow rays and shades it.  The small, long-tailed
@@ -702,17 +724,11 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
                       h->d_cnt32);
         }
         HIPCHK(hipStreamWaitEvent(side_s, h->ev_hits[level & 1], 0));
-        const uint32_t per_block = small_launch_share(n, 256u);
         float4 *local_level = h->local.as<float4>() + (size_t)level * stride;
         if (fused_shading(h, true)) {
-            LAUNCH_ON(side_s, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, true>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits,
-                      n, h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr,
-                      local_level, (int)spawn, (float4 *)nullptr, (uint32_t *)nullptr);
+            CHK((launch_bvh_shadow<MODE, true>(h, side_s, cur_rays, cur_hits, n, local_level, spawn, nullptr, nullptr)));
         } else {
-            if (S.n_lamp)
-                LAUNCH_ON(side_s, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, false>), (n + per_block - 1) / per_block, S, h->B, cur_rays,
-                          cur_hits, n, h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block,
-                          h->uniform_fetch ? h->B.nodes : nullptr, (float4 *)nullptr, 0, (float4 *)nullptr, (uint32_t *)nullptr);
+            if (S.n_lamp) CHK((launch_bvh_shadow<MODE, false>(h, side_s, cur_rays, cur_hits, n, nullptr, false, nullptr, nullptr)));
             LAUNCH_ON(side_s, HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
                       h->lamp_words, local_level, spawn, (float4 *)nullptr, (uint32_t *)nullptr);
         }
@@ -761,16 +777,10 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
         float4 *local_level = h->local.as<float4>() + (size_t)level * stride;
         bool shaded = false;
         if (h->use_bvh && fused_shading(h, false)) {
-            const uint32_t per_block = small_launch_share(n, 256u);
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, true>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
-                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr,
-                   local_level, (int)spawn, next_rays, h->d_cnt32);
+            CHK((launch_bvh_shadow<MODE, true>(h, h->stream, cur_rays, cur_hits, n, local_level, spawn, next_rays, h->d_cnt32)));
             shaded = true;
         } else if (S.n_lamp && h->use_bvh) {
-            const uint32_t per_block = small_launch_share(n, 256u);
-            LAUNCH(HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, false>), (n + per_block - 1) / per_block, S, h->B, cur_rays, cur_hits, n,
-                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, per_block, h->uniform_fetch ? h->B.nodes : nullptr,
-                   (float4 *)nullptr, 0, (float4 *)nullptr, (uint32_t *)nullptr);
+            CHK((launch_bvh_shadow<MODE, false>(h, h->stream, cur_rays, cur_hits, n, nullptr, false, nullptr, nullptr)));
         } else if (S.n_lamp) {
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
                    h->shadowq.as<float4>(), h->d_cnt32 + 1);
@@ -987,6 +997,8 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     if (const char *e = getenv("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_SHADOW_DIRECT")) h->shadow_direct = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_SHADOW_PER_BLOCK")) h->shadow_per_block = (uint32_t)std::max(64, std::min(256, atoi(e) / 64 * 64));
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
     h->n_cnt32 = std::max(8u, n_lamp + 1u);

@@ -954,6 +954,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 }
 
 // ---------------------------------------------------------------------------------------
+// k_bvh_shadow_direct: the same work without the block's list.  A lane keeps its sample and traces that sample's ray
+// to one lamp after the other; lanes whose sample casts no ray to the lamp at hand sit that lamp out.  No barriers and
+// no LDS besides the stacks, but the waves are only as full as the fraction of samples that face the lamp.
+// ---------------------------------------------------------------------------------------
+template <int MODE, bool FUSED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
+                                                    const float4 *__restrict__ hits, uint32_t n,
+                                                    uint32_t *__restrict__ occl, uint32_t lw,
+                                                    unsigned long long *__restrict__ counters, uint32_t per_block,
+                                                    const float4 *__restrict__ nodes_sc, float4 *__restrict__ local, int spawn,
+                                                    float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
+{
+    __shared__ uint32_t stack[BVH_STACK][256];
+    const uint32_t tid = threadIdx.x;
+    uint32_t j = xcd_block() * per_block + tid;
+    bool valid = tid < per_block && j < n;
+    f3 o, d; uint32_t s, aux;
+    load_ray(rays, valid ? j : 0u, o, d, s, aux);
+    float4 h = hits[valid ? j : 0u];
+    bool hit = valid && __float_as_int(h.w) >= 0;
+    Surf sf;
+    if (hit) sf = surface(S, o, d, h, false);
+    else { sf.P = mk(0.f, 0.f, 0.f); sf.N = mk(0.f, 0.f, 1.f); }
+    const f3 P = sf.P;
+    const float dotWithDir = dot(d, sf.N);
+    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
+    uint32_t occ_bits = 0u;                     // FUSED: at most 32 lamps
+    for (uint32_t l = 0; l < S.n_lamp; l++) {
+        float4 lp = S.lamp[l];
+        f3 toLamp = xyz(lp) - P;
+        const bool cast = hit && casts_shadow_ray<MODE>(dotWithDir, dot(toLamp, sf.N));
+        if (cast) {
+            bool occluded = false;
+            for (uint32_t k = 0; k < S.n_sph && !occluded; k++) {
+                float4 sp = S.sph[k];
+                float t;
+                occluded = sph_exact<MODE>(P, toLamp, xyz(sp), sp.w, t);
+            }
+            if (!occluded) {
+                TRay r = tray_make(S, B, P, toLamp);
+                Best none = best_none();
+                occluded = bvh_traverse<MODE, true>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris, nodes_sc);
+            }
+            if (occluded) {
+                if (FUSED) occ_bits |= 1u << l;
+                else atomicOr(&occl[(size_t)s * lw + (l >> 5)], 1u << (l & 31u));
+            }
+            n_rays++;
+        }
+    }
+    if (FUSED) {
+        bool bounce = false;
+        f3 bo = mk(0.f, 0.f, 0.f), bd = mk(0.f, 0.f, 1.f);
+        if (valid) {
+            load_ray(rays, j, o, d, s, aux);
+            float4 hh = hits[j];
+            if (__float_as_int(hh.w) >= -1)
+                local[s] = shade_sample<MODE>(S, o, d, hh, &occ_bits, spawn != 0, bounce, bo, bd);
+        }
+        if (spawn && next_rays) {
+            __shared__ uint32_t append_scratch[5];
+            uint32_t pos = block_append(bounce, next_count, append_scratch);
+            if (bounce) store_ray(next_rays, pos, bo, bd, s, 0u);
+        }
+    }
+    bvh_count(counters, 2, n_nodes, n_tris, n_rays);
+}
+
+// ---------------------------------------------------------------------------------------
 // k_bvh_tail: the remaining recursion levels of a small ray queue in one launch.  A lane follows its
 // ray from level `level0` to the end of its path (closest hit, shadow rays, shading, bounce, and so
 // on), writing local[level][s] exactly as k_shade does.  Used when the queue of a level is so small that

@@ -216,20 +216,23 @@ def test_timing_by_kernel_class(backends):
     assert all(none.kernel_ms[k] == 0.0 for k in range(4))
 
 
+@pytest.mark.parametrize("direct", ["0", "1"])
 @pytest.mark.parametrize("fuse", ["0", "2"])
 @pytest.mark.parametrize("tail_max", ["0", "300000"])
 @pytest.mark.parametrize("overlap", ["0", "2"])
-def test_levels_on_one_or_two_streams(overlap, tail_max, fuse, monkeypatch):
+def test_levels_on_one_or_two_streams(overlap, tail_max, fuse, direct, monkeypatch):
     """HIPEXEC_OVERLAP=2 lights every level on a side stream while the next one is traced, 0 keeps one
     stream per lane; HIPEXEC_TAIL_MAX=0 traces every level with its own launches, otherwise small ray
     queues are followed to the end of their paths by one kernel; HIPEXEC_FUSE_SHADE=2 shades inside the
-    shadow-ray kernel, 0 in a launch of its own.  The frame, the hit ids and the ray counts are those of the
+    shadow-ray kernel, 0 in a launch of its own; HIPEXEC_SHADOW_DIRECT=1 lets every lane go through the lamps with
+    its own sample, 0 compacts the block's (sample, lamp) pairs into a list first.  The frame, the hit ids and the ray counts are those of the
     oracle in every combination."""
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
     monkeypatch.setenv("HIPEXEC_OVERLAP", overlap)
     monkeypatch.setenv("HIPEXEC_TAIL_MAX", tail_max)
     monkeypatch.setenv("HIPEXEC_FUSE_SHADE", fuse)
+    monkeypatch.setenv("HIPEXEC_SHADOW_DIRECT", direct)
     fs = scenegen.small_variant("mirror").to_flat()
     W, H = 48, 132
     orc = Oracle(fs)
