@@ -175,6 +175,8 @@ struct hipexec {
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
+    uint32_t simple_from = 0u;                // HIPEXEC_SIMPLE_FROM: closest-hit launches of at least this many rays take one ray per lane
+                                              // (k_bvh_closest); smaller ones the kernel whose lanes fetch a new ray when theirs is decided
     bool shadow_direct = true;                // HIPEXEC_SHADOW_DIRECT=0: shadow rays through the block's list in LDS (k_bvh_shadow)
     uint32_t shadow_per_block = 256u;         // HIPEXEC_SHADOW_PER_BLOCK: samples owned by a block of k_bvh_shadow (multiple of 64, <= 256)
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
@@ -615,8 +617,10 @@ int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t 
         // camera rays: the 64 rays of a wave are one 8x8-pixel tile of one sub-sample and walk the hierarchy as a packet
         LAUNCH(klass_time, (k_bvh_closest_pk<MODE, false>), blocks_for(n), h->S, h->B, const_cast<float4 *>(rays), n, hits, h->d_cnt64,
                klass_count, Frame{});
-    } else if (h->bvh_refill) {
-        // camera rays arrive in coherent 8x8 tiles (one ray per lane is best), bounce rays vary widely in length
+    } else if (h->bvh_refill && n < h->simple_from) {
+        // (k_bvh_closest_p: a block owns per_block rays and its lanes take them one at a time.  It was 12 % ahead of one ray per
+        // lane with binary nodes; with 4-wide nodes and 6 waves per SIMD for both, one ray per lane is 2-5 % ahead at every
+        // launch size measured, and is what runs unless HIPEXEC_SIMPLE_FROM says otherwise.)
         uint32_t per_block = h->closest_per_block ? (uint32_t)h->closest_per_block
                                                   : small_launch_share(n, klass_count == 0 ? 256u : 768u);
         uint32_t blocks = (n + per_block - 1) / per_block;
@@ -997,6 +1001,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     if (const char *e = getenv("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_SIMPLE_FROM")) h->simple_from = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = getenv("HIPEXEC_SHADOW_DIRECT")) h->shadow_direct = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_SHADOW_PER_BLOCK")) h->shadow_per_block = (uint32_t)std::max(64, std::min(256, atoi(e) / 64 * 64));
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));

@@ -731,12 +731,12 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                      float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                      int klass)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
-    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    uint32_t j = xcd_block() * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
     load_ray(rays, valid ? j : 0u, o, d, s, aux);

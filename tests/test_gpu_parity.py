@@ -203,6 +203,22 @@ def test_camera_rays_made_by_the_packet_kernel_or_by_a_launch_of_their_own(backe
                 assert got["stats"].launches[0] == base["stats"].launches[0] + 1      # k_raygen
 
 
+def test_bounce_rays_one_per_lane_or_refilled(backends, monkeypatch):
+    """By default a lane of the closest-hit kernel of the bounce rays traces one ray; with HIPEXEC_SIMPLE_FROM above the
+    launch size the lanes of a block take the block's rays one at a time instead (k_bvh_closest_p).  Same hits, same frame."""
+    from raytracer_amd.executor import HipExecutor
+    monkeypatch.setenv("HIPEXEC_SIMPLE_FROM", "4000000000")
+    for name in ("mirror", "soup"):
+        fs, ex_default, orc = backends(name)
+        with HipExecutor(fs, device=0) as ex:
+            ref = orc.render(61, 83, mode=CPU, max_depth=3, tone=0, n_threads=8)
+            got = ex.render(61, 83, mode=CPU, max_depth=3, tone=False, algo="bvh")
+            base = ex_default.render(61, 83, mode=CPU, max_depth=3, tone=False, algo="bvh")
+            assert np.array_equal(got["ids"], ref["ids"])
+            assert np.array_equal(got["rgb"].view(np.int32), base["rgb"].view(np.int32))
+            assert got["stats"].rays == ref["stats"].rays == base["stats"].rays
+
+
 def test_timing_by_kernel_class(backends):
     """HIPEXEC_FLAG_TIME_KERNELS times every launch; with HIPEXEC_FLAG_TIME_CLASS bits only the named classes."""
     fs, ex, orc = backends("c2")
