@@ -593,7 +593,9 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
                       uint32_t &n_nodes, uint32_t &n_tris, const float4 *__restrict__ nodes_sc = nullptr)
 {
     TState st; st.node = B.root; st.sp = 0; st.limit = limit; st.found = 0u; st.overflow = 0u;
-    bvh_burst<MODE, ANY>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, 8, nodes_sc);
+    // step scheduling weight 16: the wave takes the leaf step unless twice as many lanes wait for an inner-node step
+    // (a leaf step is what ends rays and shrinks limits; measured against 8, plain majority: C2 -2 %, C3 -2.5 %)
+    bvh_burst<MODE, ANY>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, 16, nodes_sc);
     if (st.overflow) {
         n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
         st.found = bvh_linear<MODE, ANY>(B, o, d, best, n_tris) ? 1u : 0u;
