@@ -34,7 +34,7 @@ WORKLOADS = {
 }
 
 KNAMES = {"scan": ["k_primary", "k_closest", "k_anyhit_lamp", "shade/resolve"],
-          "bvh": ["k_bvh_closest_pk", "k_bvh_closest_p", "k_bvh_shadow", "shade/resolve"]}
+          "bvh": ["k_bvh_closest_pk", "k_bvh_closest", "k_bvh_shadow_direct", "shade/resolve"]}
 KLABEL = ["camera rays", "bounce rays", "shadow rays", "shading"]
 
 
@@ -51,7 +51,7 @@ def measured_traffic(kernel_class, workload, algo="bvh"):
     try:
         summ = json.load(open(files[-1]))
         for name, m in summ.items():
-            if name.startswith("rt::" + kernel_class) and m.get("launches_per_frame"):
+            if name.startswith("rt::" + kernel_class + "<") and m.get("launches_per_frame"):
                 if "hbm_read_bytes_corrected" in m and "hbm_write_bytes" in m:
                     return (m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]) / m["launches_per_frame"]
     except Exception:
