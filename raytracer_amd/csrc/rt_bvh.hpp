@@ -603,6 +603,16 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
     return st.found != 0u;
 }
 
+constexpr int SPH_LDS = 64;            // spheres a block keeps in LDS
+
+// every thread of the block must call this; returns the number of spheres held in `lds`
+DEV uint32_t spheres_to_lds(const DScene &S, float4 *lds) {
+    const uint32_t n_sl = min(S.n_sph, (uint32_t)SPH_LDS);
+    if (threadIdx.x < n_sl) lds[threadIdx.x] = S.sph[threadIdx.x];
+    __syncthreads();
+    return n_sl;
+}
+
 // Workgroups are handed to the 8 XCDs in turn (workgroup b runs on XCD b mod 8), each XCD with an L2 of its own.
 // Runs of XCD_RUN consecutive work items go to one XCD, the runs to the XCDs in turn: neighbouring tiles share an L2
 // and the XCDs still get the same mix of cheap and expensive parts of the image.
@@ -969,7 +979,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                                                     float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
+    // The spheres are tested one after the other for every shadow ray, each test behind a load of its own: from LDS
+    // that load takes a tenth of the time it takes from the vector cache (first SPH_LDS spheres; the rest from memory).
+    // C5 (16 spheres) -2.5 %; the closest-hit kernels test the spheres once per ray and gain nothing from the same copy.
+    __shared__ float4 sph_lds[SPH_LDS];
     const uint32_t tid = threadIdx.x;
+    const uint32_t n_sl = spheres_to_lds(S, sph_lds);
     uint32_t j = xcd_block() * per_block + tid;
     bool valid = tid < per_block && j < n;
     f3 o, d; uint32_t s, aux;
@@ -989,7 +1004,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         const bool cast = hit && casts_shadow_ray<MODE>(dotWithDir, dot(toLamp, sf.N));
         if (cast) {
             bool occluded = false;
-            for (uint32_t k = 0; k < S.n_sph && !occluded; k++) {
+            for (uint32_t k = 0; k < n_sl && !occluded; k++) {
+                float4 sp = sph_lds[k];
+                float t;
+                occluded = sph_exact<MODE>(P, toLamp, xyz(sp), sp.w, t);
+            }
+            for (uint32_t k = n_sl; k < S.n_sph && !occluded; k++) {
                 float4 sp = S.sph[k];
                 float t;
                 occluded = sph_exact<MODE>(P, toLamp, xyz(sp), sp.w, t);
