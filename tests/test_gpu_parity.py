@@ -219,6 +219,21 @@ def test_bounce_rays_one_per_lane_or_refilled(backends, monkeypatch):
             assert got["stats"].rays == ref["stats"].rays == base["stats"].rays
 
 
+def test_more_spheres_than_the_shadow_kernel_keeps_in_lds():
+    """The shadow-ray kernel keeps the first 64 spheres in LDS and reads the others from memory: 90 spheres, 3 lamps."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = scenegen.scene_c5(cells=12, n_lamps=3, n_spheres=90).to_flat()
+    orc = Oracle(fs)
+    with HipExecutor(fs, device=0) as ex:
+        for mode in (CPU, CL):
+            ref = orc.render(72, 40, mode=mode, max_depth=0, tone=0, n_threads=8)
+            got = ex.render(72, 40, mode=mode, max_depth=0, tone=False, algo="bvh")
+            assert np.array_equal(got["ids"], ref["ids"])
+            assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+            assert got["stats"].rays_shadow == ref["stats"].rays_shadow
+
+
 def test_timing_by_kernel_class(backends):
     """HIPEXEC_FLAG_TIME_KERNELS times every launch; with HIPEXEC_FLAG_TIME_CLASS bits only the named classes."""
     fs, ex, orc = backends("c2")
