@@ -430,9 +430,17 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             }
         } else if (at_leaf) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
+            // the records of the first two triangles are requested together (the array is padded by one record), so a
+            // two-triangle leaf waits for memory once
+            float4 q[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) q[i] = T[3 * (size_t)first + i];
             for (uint32_t k = first; k < first + cnt; k++) {
                 if (ANY && found) continue;
-                float4 e0 = T[3 * (size_t)k], e1 = T[3 * (size_t)k + 1], e2 = T[3 * (size_t)k + 2];
+                float4 e0, e1, e2;
+                if (k == first) { e0 = q[0]; e1 = q[1]; e2 = q[2]; }
+                else if (k == first + 1u) { e0 = q[3]; e1 = q[4]; e2 = q[5]; }
+                else { e0 = T[3 * (size_t)k]; e1 = T[3 * (size_t)k + 1]; e2 = T[3 * (size_t)k + 2]; }
                 n_tris++;
                 float t, u, v;
                 if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
