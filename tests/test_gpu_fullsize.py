@@ -32,6 +32,35 @@ def _check_blocks(fs, got, W, H, depth, mode, blocks, lin=None):
     assert n_hit > 0
 
 
+@pytest.mark.parametrize("fractional", [False, True])
+def test_c1_full_size_whole_frame(fractional):
+    """Benchmark config 1 at its stated size: ~1k triangles + 8 spheres, 1 lamp, 640x480, 4 spp, primary + shadow
+    rays (ray_tracer.cpp:7-54 with reflection compiled out).  The whole frame against the oracle, both algorithms;
+    `fractional` moves sphere and lamp coordinates off the integers (truncated by the loader, scene.cpp:97-99,112-114)."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = scenegen.scene_c1(fractional=fractional).to_flat()
+    W, H = 640, 480
+    ref = Oracle(fs).render(W, H, mode=_abi.HIPEXEC_MODE_CPU, max_depth=0, tone=1, n_threads=16)
+    assert (ref["ids"] >= fs.n_tri).any() and (ref["ids"] == -1).any() and ((ref["ids"] >= 0) & (ref["ids"] < fs.n_tri)).any()
+    with HipExecutor(fs, device=0) as ex:
+        for algo in ("bvh", "scan"):
+            got = ex.render(W, H, max_depth=0, algo=algo)
+            lin = ex.render(W, H, max_depth=0, tone=False, want_ids=False, algo=algo)["rgb"]
+            assert np.array_equal(got["ids"], ref["ids"]), f"{algo}: {(got['ids'] != ref['ids']).sum()} hit ids differ"
+            assert ulp_diff(lin, ref["linear"]).max() <= 4
+            assert_image_parity(got["rgb"], ref["rgb"])
+            gs, rs = got["stats"], ref["stats"]
+            assert gs.rays_primary == rs.rays_primary == W * H * 4
+            assert gs.rays_shadow == rs.rays_shadow > 0 and gs.rays_bounce == rs.rays_bounce == 0
+            assert gs.bvh_stack_overflows == 0
+        # the reference's own GPU path (1 sample per pixel, cl_kernels.c rules) on the same scene and size
+        ref_cl = Oracle(fs).render(W, H, mode=_abi.HIPEXEC_MODE_CL, max_depth=0, tone=1, n_threads=16)
+        got_cl = ex.render(W, H, mode=_abi.HIPEXEC_MODE_CL)
+        assert np.array_equal(got_cl["ids"], ref_cl["ids"])
+        assert_image_parity(got_cl["rgb"], ref_cl["rgb"])
+
+
 def test_c2_full_size_depth3():
     """Benchmark config 2: 100 352 triangles, 1920x1080, 4 spp, depth-3 reflections."""
     from raytracer_amd.executor import HipExecutor
@@ -99,6 +128,48 @@ def test_c5_many_lights_4k_strip():
     _check_blocks(fs, a, W, H, 0, _abi.HIPEXEC_MODE_CPU, blocks)
     untouched = np.ones(H // 8, bool); untouched[tiles] = False
     assert (a["ids"].reshape(H // 8, 8, W, 4)[untouched] == -3).all()      # rows of other tiles are left alone
+
+
+def test_c5_whole_4k_frame_in_one_call():
+    """Benchmark config 5 as the benchmark runs it: the whole 3840x2160 frame in one call (33 M samples, 16 lamps,
+    one batch).  Oracle on a grid of blocks, repeat render bit-identical, two interleaved shards compose to it."""
+    from raytracer_amd.executor import HipExecutor
+    fs = scenegen.scene_c5().to_flat()
+    W, H = 3840, 2160
+    with HipExecutor(fs, device=0) as ex:
+        a = ex.render(W, H, max_depth=0)
+        b = ex.render(W, H, max_depth=0, want_ids=False)
+        assert np.array_equal(a["rgb"].view(np.int32), b["rgb"].view(np.int32)), "render is not deterministic"
+        img = np.full((H, W, 3), -1, np.float32)
+        rays = 0
+        for r in range(2):
+            p = ex.render(W, H, max_depth=0, tile_first=r, tile_step=2, out=img, want_ids=False)
+            rays += p["stats"].rays
+        assert np.array_equal(img.view(np.int32), a["rgb"].view(np.int32)), "tile shards do not compose"
+    st = a["stats"]
+    assert st.rays_primary == W * H * 4 and st.rays_shadow > st.rays_primary and st.rays == rays
+    assert st.bvh_stack_overflows == 0
+    ids = a["ids"]
+    assert ids.min() >= -1 and ids.max() < fs.n_tri + fs.n_sph and (ids >= fs.n_tri).any() and (ids == -1).any()
+    _check_blocks(fs, a, W, H, 0, _abi.HIPEXEC_MODE_CPU, _blocks(W, H, 5, 4))
+
+
+def test_c4_bilinear_block_grid():
+    """Benchmark config 4 names bilinear sampling, which the reference does not have (tex_image.h:34-44 is
+    nearest-texel): the opt-in mode at full size against its definition in the oracle."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = scenegen.scene_c4().to_flat()
+    W, H = 1920, 1080
+    with HipExecutor(fs, device=0) as ex:
+        a = ex.render(W, H, bilinear=True)
+        n = ex.render(W, H, want_ids=False)
+    assert not np.array_equal(a["rgb"], n["rgb"])              # the mode changes textured pixels
+    orc = Oracle(fs)
+    for (x, y) in _blocks(W, H, 4, 3):
+        ref = orc.render_region(W, H, x, y, 8, 8, mode=_abi.HIPEXEC_MODE_CPU, max_depth=0, tone=1, n_threads=1, bilinear=True)
+        assert np.array_equal(a["ids"][y:y + 8, x:x + 8], ref["ids"])
+        assert_image_parity(a["rgb"][y:y + 8, x:x + 8], ref["rgb"], min_frac=1.0)
 
 
 def test_c4_texture_heavy_cl_mode():
