@@ -274,6 +274,24 @@ int hipexec_closest_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n,
 int hipexec_any_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, char *hits);
 
 /*
+ * hipexec_any_hits for callers that cannot allocate.  No counterpart in the reference; it exists for
+ * callers that may not reach hipMalloc / hipFree: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same occlusion test as hipexec_any_hits, but
+ *   - d_rays6 and d_hits are DEVICE pointers on the executor's device (n rays of 6 floats; n chars,
+ *     OR-ed into like hipexec_any_hits does);
+ *   - the work is enqueued on the executor's stream and the call returns without waiting
+ *     (hipexec_sync() or the caller's own stream ordering makes the result visible);
+ *   - the ray records, occlusion words and work counters the kernels need live in a fixed device
+ *     array of the library (about 9 MiB per GPU, held until the process ends) instead of grown
+ *     buffers, so the call performs no hipMalloc, hipFree or other allocating call;
+ *   - n must not exceed HIPEXEC_STATIC_MAX_RAYS (HIPEXEC_E_LIMIT otherwise).
+ * All calls on one GPU share that array: calls that overlap on one GPU (two executors, or two
+ * streams) race; one executor's calls are ordered by its stream.
+ */
+#define HIPEXEC_STATIC_MAX_RAYS (1u << 18)
+int hipexec_any_hits_static(hipexec_t *h, int mode, const float *d_rays6, uint32_t n, char *d_hits);
+
+/*
  * Replaces traceRaysCl (ray_tracer_cl.cpp:108-178, HIPEXEC_MODE_CL) / traceRay
  * (ray_tracer.cpp:156-201, HIPEXEC_MODE_CPU) for a batch of rays: colours3[i] ([n][3]
  * floats, host) is accumulated into (+=) as the reference does, caller pre-zeros.

@@ -18,6 +18,7 @@ HIPEXEC_FLAG_BILINEAR = 8
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
 ABI_VERSION = 2
+STATIC_MAX_RAYS = 1 << 18
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -107,6 +108,7 @@ PROTOTYPES = {
     "hipexec_sync": (C.c_int, [C.c_void_p]),
     "hipexec_closest_hits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
     "hipexec_any_hits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "hipexec_any_hits_static": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
     "hipexec_trace_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]),
     "hipexec_last_error": (C.c_char_p, []),
     "hipexec_abi_version": (C.c_int, []),

@@ -125,6 +125,24 @@ constexpr uint64_t BATCH_MAX_SAMPLES = 64ull << 20;          // samples per batc
 constexpr uint32_t TAIL_MAX_RAYS = 300000u;                    // see use_tail
 constexpr int N_CNT64 = 17;                                  // device counters, see call_end
 
+// Fixed work memory of hipexec_any_hits_static (one copy per GPU, held until the process ends):
+// [0, 256) work counters, then the ray records (32 bytes per ray), then one occlusion word per ray.
+constexpr size_t STATIC_CNT_BYTES = 256;
+constexpr size_t STATIC_REC_BYTES = (size_t)HIPEXEC_STATIC_MAX_RAYS * 32;
+constexpr size_t STATIC_OCC_BYTES = (size_t)HIPEXEC_STATIC_MAX_RAYS * 4;
+constexpr size_t STATIC_BYTES = STATIC_CNT_BYTES + STATIC_REC_BYTES + STATIC_OCC_BYTES;
+static_assert(N_CNT64 * sizeof(unsigned long long) <= STATIC_CNT_BYTES, "counters fit their slot");
+constexpr int STATIC_MAX_DEVICES = 64;
+
+}  // namespace
+
+// In host code this name is only a handle for hipGetSymbolAddress: the address the kernels use is
+// g_static_ptr[device], looked up once per device by static_scratch_init().
+static __device__ __align__(256) unsigned char g_static_scratch[STATIC_BYTES];
+
+namespace {
+unsigned char *g_static_ptr[STATIC_MAX_DEVICES] = {};
+std::mutex g_static_mutex;
 }  // namespace
 
 struct hipexec {
@@ -184,6 +202,19 @@ struct hipexec {
 };
 
 namespace {
+
+// Address of this device's copy of g_static_scratch; `device` must be the current device.
+int static_scratch_init(int device)
+{
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return HIPEXEC_OK;       // such a device has no static entry point
+    std::lock_guard<std::mutex> lk(g_static_mutex);
+    if (g_static_ptr[device]) return HIPEXEC_OK;
+    void *p = nullptr;
+    HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+    if (!p) return fail(HIPEXEC_E_DEVICE, "hipGetSymbolAddress returned a null address for device %d", device);
+    g_static_ptr[device] = static_cast<unsigned char *>(p);
+    return HIPEXEC_OK;
+}
 
 // Scene memory comes from a few large chunks (one hipMalloc / hipFree per chunk instead of one per
 // array: creating and destroying an executor per frame, as ray_tracer_cl.cpp:14 does, stays cheap).
@@ -979,6 +1010,14 @@ __global__ void k_strip_alpha(const float4 *__restrict__ rgba, size_t n, float *
     rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
 }
 
+// hits[i] |= bit 0 of bits[i] (computeAnyHitsCl ORs into the caller's array, ray_tracer_cl.cpp:255,260)
+__global__ void k_or_hits(const uint32_t *__restrict__ bits, uint32_t n, char *__restrict__ hits)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    hits[i] = (hits[i] || (bits[i] & 1u)) ? 1 : 0;
+}
+
 int import_rays(hipexec *h, const float *rays6, uint32_t n)
 {
     CHK(h->stage_in.reserve((size_t)n * 24));
@@ -1043,6 +1082,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
     if (!h) return fail(HIPEXEC_E_NOMEM, "out of host memory");
     h->device = device;
     int rc = [&]() -> int {
+        CHK(static_scratch_init(device));
         CHK(create_lane_resources(h, scene->n_lamp));
         if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
         if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
@@ -1278,6 +1318,45 @@ int hipexec_any_hits(hipexec_t *h, int mode, const float *rays6, uint32_t n, cha
         for (uint32_t i = 0; i < m; i++) hits[off + i] = (hits[off + i] || (bits[i] & 1u)) ? 1 : 0;
     }
     return call_end(h, nullptr);
+}
+
+int hipexec_any_hits_static(hipexec_t *h, int mode, const float *d_rays6, uint32_t n, char *d_hits)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (mode != HIPEXEC_MODE_CPU && mode != HIPEXEC_MODE_CL) return fail(HIPEXEC_E_INVALID, "unknown mode %d", mode);
+    if (n == 0) return HIPEXEC_OK;
+    if (!d_rays6 || !d_hits) return fail(HIPEXEC_E_INVALID, "d_rays6/d_hits is NULL");
+    if (n > HIPEXEC_STATIC_MAX_RAYS)
+        return fail(HIPEXEC_E_LIMIT, "%u rays exceed the %u of the fixed work memory (HIPEXEC_STATIC_MAX_RAYS)", n, HIPEXEC_STATIC_MAX_RAYS);
+    unsigned char *base = (h->device >= 0 && h->device < STATIC_MAX_DEVICES) ? g_static_ptr[h->device] : nullptr;
+    if (!base) return fail(HIPEXEC_E_DEVICE, "no fixed work memory on device %d", h->device);
+    HIPCHK(hipSetDevice(h->device));
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(base);
+    float4 *recs = reinterpret_cast<float4 *>(base + STATIC_CNT_BYTES);
+    uint32_t *bits = reinterpret_cast<uint32_t *>(base + STATIC_CNT_BYTES + STATIC_REC_BYTES);
+    hipStream_t st = h->stream;
+    // the array keeps the last call's contents: counters and occlusion words start at zero, the records are overwritten
+    HIPCHK(hipMemsetAsync(cnt, 0, STATIC_CNT_BYTES, st));
+    HIPCHK(hipMemsetAsync(bits, 0, (size_t)n * 4, st));
+    const dim3 blk(256), grid(blocks_for(n));
+    hipLaunchKernelGGL(k_import_rays, grid, blk, 0, st, d_rays6, n, recs);
+    HIPCHK(hipGetLastError());
+    const bool bvh = h->bvh_default && h->bvh_ok;
+    if (bvh) {
+        if (mode == HIPEXEC_MODE_CL) hipLaunchKernelGGL((k_bvh_anyhit<HIPEXEC_MODE_CL>), grid, blk, 0, st, h->S, h->B, recs, n, bits, 1u, cnt);
+        else hipLaunchKernelGGL((k_bvh_anyhit<HIPEXEC_MODE_CPU>), grid, blk, 0, st, h->S, h->B, recs, n, bits, 1u, cnt);
+    } else {
+        constexpr int R = 2;
+        const dim3 sgrid(blocks_for(((uint64_t)n + 64 * R - 1) / (64 * R) * 64));
+        DScene S = h->S;
+        S.bilinear = 0u;
+        if (mode == HIPEXEC_MODE_CL) hipLaunchKernelGGL((k_anyhit<HIPEXEC_MODE_CL, R>), sgrid, blk, 0, st, S, recs, n, bits, 1u, cnt);
+        else hipLaunchKernelGGL((k_anyhit<HIPEXEC_MODE_CPU, R>), sgrid, blk, 0, st, S, recs, n, bits, 1u, cnt);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_or_hits, grid, blk, 0, st, bits, n, d_hits);
+    HIPCHK(hipGetLastError());
+    return HIPEXEC_OK;
 }
 
 int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6, uint32_t n, float *colours3,

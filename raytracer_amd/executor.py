@@ -144,6 +144,11 @@ class HipExecutor:
         self._check(self._lib.hipexec_any_hits(self._h, int(mode), r.ctypes.data, r.shape[0], hits.ctypes.data))
         return hits
 
+    def any_hits_static(self, d_rays6: int, n: int, d_hits: int, mode=HIPEXEC_MODE_CL):
+        """any_hits on device pointers through the library's fixed work memory: allocates nothing, asynchronous
+        on the executor's stream (sync() before reading d_hits), at most _abi.STATIC_MAX_RAYS rays."""
+        self._check(self._lib.hipexec_any_hits_static(self._h, int(mode), C.c_void_p(d_rays6), int(n), C.c_void_p(d_hits)))
+
     def trace_rays(self, rays6, mode=HIPEXEC_MODE_CL, max_depth=0, colours=None, want_stats=False):
         r = self._rays(rays6)
         if colours is None:
