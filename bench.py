@@ -2,29 +2,42 @@
 """Headline benchmark: Mrays/s (primary + shadow + bounce rays) of the tracing hot path.
 
 One step = one frame of the workload, traced by the HIP executor with the scene resident in
-HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the frame is split
-into interleaved 8-row tiles, every rank traces its tiles, and the tiles are gathered to rank 0
-over RCCL inside the timed region; total work is fixed, so scaling is "strong".
+HBM.  With N > 1 (one process per GPU; `--gpus N` without a launcher starts the N ranks itself
+through torch.distributed.run) the frame is split into interleaved 8-row tiles, every rank traces
+its tiles, and the tiles are gathered to rank 0 over RCCL inside the timed region; total work is
+fixed, so scaling is "strong".
 
-Prints ONE JSON line on rank 0 with the whole-job rate, the roofline of the dominant kernel
-(HIP-event times taken by the executor on the stream its kernels run on) and, at N = 1, the
-CPU oracle timed on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0 with the whole-job rate and, at N = 1:
+  roofline        the dominant kernel class of the default algorithm (hierarchy traversal): FLOP the kernel
+                  executed (counted on the device) / its HIP-event time / vector-FP32 peak;
+  roofline_brute  the same frame traced by the reference's own algorithm (every ray against every triangle,
+                  index order), 1 warm-up + 2 frames: executed packed-FP32 instructions / event time / peak;
+  cpu_baseline    the CPU oracle (restatement of ray_tracer.cpp) on a bounded sample of the same frame, one
+                  core and all cores.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test
+F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test of the reference's scans
 F_NODE = 190.0                       # FLOP per visited hierarchy node (cone term + four enlarged-box slab tests of 46, see bvh_box)
-PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA)
+PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA: 256 CU x 4 SIMD x 16 lanes x 2 x 2 FLOP x 2.4 GHz)
+# Packed-FP32 filter of the index-order scans, FLOP per lane: camera / lamp-line records take 3 packed multiplies
+# (2 FLOP per lane each) + 6 packed FMAs (4 each) per PAIR of triangles and ray; the records for arbitrary rays
+# 3 + 15.  A group that passes the filter is re-filtered per triangle (scalar form: 3 mul + 6 fma, or 3 + 15).
+F_PAIR_CAM, F_PAIR_GEN = 3 * 2 + 6 * 4, 3 * 2 + 15 * 4
+F_ONE_CAM, F_ONE_GEN = 3 * 1 + 6 * 2, 3 * 1 + 15 * 2
 
 WORKLOADS = {
-    # name: (scene builder kwargs, width, height, max_depth, description)
+    # name: (scene builder, kwargs, width, height, max_depth, description)
     "c2": ("scene_c2", {}, 1920, 1080, 3, "C2: 100352-tri textured heightfield + 4 mirror spheres, 2 lamps, 1920x1080, 4 spp, depth-3 reflections"),
     "c3": ("scene_c2", {}, 3840, 2160, 5, "C3: C2 scene at 3840x2160, depth-5 reflections"),
     "c1": ("scene_c1", {}, 640, 480, 0, "C1: ~1k tris + 8 spheres, 1 lamp, 640x480, 4 spp, depth 0"),
@@ -38,11 +51,40 @@ KNAMES = {"scan": ["k_primary", "k_closest", "k_anyhit_lamp", "shade/resolve"],
 KLABEL = ["camera rays", "bounce rays", "shadow rays", "shading"]
 
 
-def measured_traffic(kernel_class, workload, algo="bvh"):
-    """HBM bytes per launch of a kernel class from the newest committed PMC summary
-    (profiles/rNN_<algo>_pmc_summary.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE, collected
-    in separate rocprofv3 --pmc passes on the C2 workload).  None when no summary applies."""
-    import glob
+# ----------------------------------------------------------------------------------------
+# launcher
+# ----------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks_if_needed(args, argv):
+    """`--gpus N` with N > 1 outside a launcher: start the N ranks (one process per GPU) and return their exit
+    code; inside a launcher: check that its world size is the one asked for.  Runs before anything touches a GPU.
+    Returns None when this process is a rank and should go on."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        if args.gpus <= 1:
+            return None
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+        return subprocess.call(cmd)
+    if int(world_env) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks", file=sys.stderr)
+        return 2
+    return None
+
+
+# ----------------------------------------------------------------------------------------
+# evidence from the committed profiles
+# ----------------------------------------------------------------------------------------
+def pmc_quote(kernel_class, workload, algo):
+    """Counter-derived figures of a kernel class from the newest committed PMC summary of this algorithm
+    (profiles/rNN_<algo>_pmc_summary.json, rocprofv3 --pmc passes on the C2 workload): VALU utilisation, live lanes
+    per issued VALU instruction, L2 hit rate, resident waves per SIMD, HBM bytes per launch (FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE).  None when no summary applies."""
     if workload != "c2":
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{algo}_pmc_summary.json")))
@@ -50,18 +92,43 @@ def measured_traffic(kernel_class, workload, algo="bvh"):
         return None
     try:
         summ = json.load(open(files[-1]))
-        for name, m in summ.items():
-            if name.startswith("rt::" + kernel_class + "<") and m.get("launches_per_frame"):
-                if "hbm_read_bytes_corrected" in m and "hbm_write_bytes" in m:
-                    return (m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]) / m["launches_per_frame"]
     except Exception:
         return None
+    for name, m in summ.items():
+        if not name.startswith("rt::" + kernel_class + "<"):
+            continue
+        c = m.get("counters", {})
+        q = {"source": os.path.relpath(files[-1], ROOT), "kernel": name}
+        for k in ("valu_utilisation", "l2_hit_rate", "occupancy_waves_per_simd"):
+            if k in m:
+                q[k] = m[k]
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            q["live_lane_fraction"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        if c.get("SQ_WAVE_CYCLES"):
+            q["wait_fraction_of_wave_cycles"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        if m.get("launches_per_frame") and "hbm_read_bytes_corrected" in m and "hbm_write_bytes" in m:
+            q["hbm_bytes_per_launch"] = (m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]) / m["launches_per_frame"]
+        return q
     return None
 
 
-def class_flops(st, k, n_sph):
-    """Algorithmic FLOP of a ray class: the tests of the reference's linear scans (every
-    triangle and sphere per closest-hit ray; up to the first occluder per shadow ray)."""
+def limiter_of(q):
+    """What the counters say holds the kernel back (the roofline's unit stays FLOP/s against the VALU peak)."""
+    if not q or "valu_utilisation" not in q:
+        return None
+    if q["valu_utilisation"] >= 0.8:
+        return "VALU issue (SIMDs issue vector instructions >= 80 % of the time)"
+    return ("latency and divergence: SIMDs issue VALU instructions %.0f %% of the time with %.0f %% of the lanes live, "
+            "%.1f waves per SIMD resident; neither HBM nor FP32 throughput is saturated"
+            % (100 * q["valu_utilisation"], 100 * q.get("live_lane_fraction", 0.0), q.get("occupancy_waves_per_simd", 0.0)))
+
+
+# ----------------------------------------------------------------------------------------
+# FLOP models
+# ----------------------------------------------------------------------------------------
+def scan_equiv_flops(st, k, n_sph):
+    """Algorithmic FLOP of a ray class under the reference's linear scans: every triangle and sphere per
+    closest-hit ray; up to the first occluder per shadow ray."""
     if k == 0:
         return st.tests_tri_primary * F_TRI + st.rays_primary * n_sph * F_SPH
     if k == 1:
@@ -71,16 +138,43 @@ def class_flops(st, k, n_sph):
     return 0.0
 
 
-def executed_flops(st, k, n_sph):
-    """FLOP the hierarchy kernels actually evaluated for a ray class (node visits + exact tests)."""
-    rays = [st.rays_primary, st.rays_bounce, st.rays_shadow][k] if k < 3 else 0
+def executed_flops_bvh(st, k, n_sph):
+    """FLOP the hierarchy kernels evaluated for a ray class (node visits + exact tests + sphere tests, counted on the device)."""
     if k >= 3:
         return 0.0
+    rays = [st.rays_primary, st.rays_bounce, st.rays_shadow][k]
     return st.bvh_nodes[k] * F_NODE + st.bvh_tests[k] * F_TRI + rays * n_sph * F_SPH
 
 
+def executed_flops_scan(st, k):
+    """FLOP of the packed-FP32 filter instructions the scan kernels executed for a ray class: per (wave, scanned
+    128-triangle chunk) 64 pairs x 64 lanes x rays per lane x the pair filter; per (wave, group that passed) 4 triangles
+    re-filtered one by one.  The exact tests of the few survivors (44 FLOP each) are left out, so this undercounts."""
+    if k >= 3:
+        return 0.0
+    rays_per_lane = [4, int(os.environ.get("HIPEXEC_CLOSEST_R", "3")), int(os.environ.get("HIPEXEC_ANYHIT_R", "2"))][k]
+    f_pair, f_one = [(F_PAIR_CAM, F_ONE_CAM), (F_PAIR_GEN, F_ONE_GEN), (F_PAIR_CAM, F_ONE_CAM)][k]
+    per_lane = st.scanned_chunks[k] * 64.0 * f_pair + st.exact_groups[k] * 4.0 * f_one
+    return per_lane * 64.0 * rays_per_lane
+
+
+# ----------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(fs, W, H, depth, budget_s=20.0):
-    """CPU oracle (restatement of ray_tracer.cpp) on a regular grid of 8x8-pixel blocks of the frame."""
+    """CPU oracle (oracle/rt_oracle.c, a restatement of ray_tracer.cpp built with the reference's flags) on a regular
+    grid of 8x8-pixel blocks of the frame: one thread, then a block-parallel pool like renderParallel
+    (ray_tracer.cpp:57-153) on up to 16 threads."""
     import numpy as np
     from oracle.binding import Oracle
     threads = max(1, min(16, os.cpu_count() or 1))
@@ -92,19 +186,66 @@ def cpu_baseline(fs, W, H, depth, budget_s=20.0):
         ys = np.linspace(0, H - 8, g).astype(int) // 8 * 8
         return np.array([(x, y, 8, 8) for y in ys for x in xs], dtype=np.int32)
 
-    # probe with `threads` blocks to size the sample for ~budget_s
-    probe = blocks(threads)
-    t0 = time.perf_counter(); st = orc.render_blocks(W, H, probe, max_depth=depth, n_threads=threads); dt = time.perf_counter() - t0
-    rate = st.rays / max(dt, 1e-9)
-    n = int(min(4096, max(threads, (budget_s * rate) / max(1.0, st.rays / probe.shape[0]))))
-    sample = blocks(n)
-    t0 = time.perf_counter(); st = orc.render_blocks(W, H, sample, max_depth=depth, n_threads=threads); dt = time.perf_counter() - t0
-    return {"value": st.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{sample.shape[0]} blocks of 8x8 pixels on a regular grid of the {W}x{H} frame, full depth "
-                      f"({st.rays} rays, {dt:.1f} s, block-parallel pthread pool)"}
+    def timed(n_blocks, n_threads):
+        b = blocks(n_blocks)
+        t0 = time.perf_counter(); st = orc.render_blocks(W, H, b, max_depth=depth, n_threads=n_threads); dt = time.perf_counter() - t0
+        return st.rays, dt, b.shape[0]
+
+    def leg(n_threads, budget):
+        rays, dt, nb = timed(max(4, n_threads), n_threads)                       # probe sizes the sample
+        n = int(min(4096, max(n_threads, budget * (rays / max(dt, 1e-9)) / max(1.0, rays / nb))))
+        rays, dt, nb = timed(n, n_threads)
+        return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": n_threads,
+                "sample": f"{nb} blocks of 8x8 pixels on a regular grid of the {W}x{H} frame, full depth ({rays} rays, {dt:.1f} s)"}
+
+    one = leg(1, 0.3 * budget_s)
+    allc = leg(threads, 0.7 * budget_s)
+    allc.update({"kind": "port",
+                 "kind_note": "oracle restatement of ray_tracer.cpp (oracle/rt_oracle.c, -O2, no -march, no fast-math, block-parallel "
+                              "pthread pool); the reference itself cannot be compiled here (its glm dependency is absent)",
+                 "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "one_core": one})
+    return allc
 
 
-def main():
+# ----------------------------------------------------------------------------------------
+# functional self-test of the multi-process path on CPU (gloo): no GPU, no executor, no rate
+# ----------------------------------------------------------------------------------------
+def selftest_cpu(args, rank, world):
+    """The launcher, rendezvous, tile partition, gather and max-over-ranks timing of this file with a stand-in for
+    the executor that writes each tile's frame index into its rows.  Prints a line marked "selftest": true."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.dist import gather_frame, local_tiles, max_local_tiles
+    _, _, W, H, _, desc = WORKLOADS[args.workload]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    tmax = max_local_tiles(H, world)
+    out = torch.zeros((tmax * 8, W, 4), dtype=torch.float32)
+    ok = True
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        for j in range(local_tiles(H, rank, world)):
+            out[8 * j:8 * j + 8] = float(rank + j * world)
+        frame = gather_frame(out, H)
+        if rank == 0:
+            ok = ok and bool(torch.equal(frame[:, 0, 0], (torch.arange(H) // 8).float()))
+    elapsed = time.perf_counter() - t0
+    seen = torch.ones(1)
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(seen); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "ok": ok, "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps,
+                          "warmup": args.warmup, "elapsed_s": float(t[0]), "data": "stand-in executor on CPU (gloo): not a measurement",
+                          "config": {"workload": desc}}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ----------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -114,23 +255,30 @@ def main():
                     help="bvh: hierarchy traversal (default); scan: index-order scans with chunk culling; "
                          "brute: index-order scans of every triangle, the reference's own work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-brute", action="store_true", help="leave out the roofline_brute leg (1 warm-up + 2 frames of full scans)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
+    ap.add_argument("--selftest-cpu", action="store_true", help="functional check of the multi-process path on CPU (gloo), no GPU")
+    args = ap.parse_args(argv)
 
-    import numpy as np
+    rc = launch_ranks_if_needed(args, argv)
+    if rc is not None:
+        return rc
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
+
     import torch
     import torch.distributed as dist
     from raytracer_amd import _abi, scenegen
     from raytracer_amd.dist import gather_frame, max_local_tiles
     from raytracer_amd.executor import HipExecutor
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
+    if world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -142,6 +290,7 @@ def main():
         os.environ["HIPEXEC_NO_CULL"] = "1"
     algo = "bvh" if args.algo == "bvh" else "scan"
     ex = HipExecutor(fs, device=local_rank)
+    os.environ.pop("HIPEXEC_NO_CULL", None)
     stream = torch.cuda.Stream(device=dev)
     ex.set_stream(stream.cuda_stream)
     tmax = max_local_tiles(H, world)
@@ -149,13 +298,13 @@ def main():
     st = _abi.Stats()
     frame = None
 
-    def step(time_kernels):
+    def step(time_kernels, exe=None, a=None):
         nonlocal frame
         with torch.cuda.stream(stream):
-            ex.render_device(W, H, out.data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
-                             time_kernels=time_kernels, stats=st, algo=algo)
+            (exe or ex).render_device(W, H, out.data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
+                                      time_kernels=time_kernels, stats=st, algo=a or algo)
             frame = gather_frame(out, H)
-            ex.sync()
+            (exe or ex).sync()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -163,16 +312,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # The algorithmic test counts of the reference's scans are a property of the frame; only the
-    # index-order scans can count the shadow-ray part, so take them from one untimed scan frame.
+    # The test counts of the reference's scans are a property of the frame; only the index-order scans can count the
+    # shadow-ray part, so they come from one untimed scan frame (reported as scan_equivalent, never as the roofline).
     ref_flops = None
-    if algo == "bvh" and rank == 0:
-        st_scan = _abi.Stats()
-        with torch.cuda.stream(stream):
-            ex.render_device(W, H, out.data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
-                             stats=st_scan, algo="scan")
-            ex.sync()
-        ref_flops = [class_flops(st_scan, k, fs.n_sph) for k in range(3)]
+    if algo == "bvh" and rank == 0 and world == 1:
+        step(False, a="scan")
+        ref_flops = [scan_equiv_flops(st, k, fs.n_sph) for k in range(3)]
     # One untimed frame with every kernel class timed picks the dominant class; the timed steps then bracket only that
     # class's launches with events (every timed launch costs two event records on its stream).
     for _ in range(args.warmup):
@@ -180,56 +325,55 @@ def main():
     step(True)
     probe_ms = [float(st.kernel_ms[k]) for k in range(4)]
     dom = max(range(3), key=lambda k: probe_ms[k])
-    agg = {k: 0 for k in ("rays", "ms0", "ms1", "ms2", "ms3", "f0", "f1", "f2", "x0", "x1", "x2", "l0", "l1", "l2", "l3")}
+    agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop")}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step([dom])
         agg["rays"] += st.rays
-        for k in range(4):
-            agg[f"ms{k}"] += st.kernel_ms[k]; agg[f"l{k}"] += st.launches[k]
-        for k in range(3):
-            agg[f"f{k}"] += ref_flops[k] if ref_flops is not None else class_flops(st, k, fs.n_sph)
-            agg[f"x{k}"] += executed_flops(st, k, fs.n_sph)
+        agg["ms"] += st.kernel_ms[dom]; agg["launches"] += st.launches[dom]
+        agg["exec_flop"] += executed_flops_bvh(st, dom, fs.n_sph) if algo == "bvh" else executed_flops_scan(st, dom)
+        agg["equiv_flop"] += ref_flops[dom] if ref_flops is not None else scan_equiv_flops(st, dom, fs.n_sph)
     fence()
     elapsed = time.perf_counter() - t0
+    lanes = int(st.lanes)
 
-    t = torch.tensor([elapsed, float(agg["rays"])], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(agg["rays"]), 1.0], dtype=torch.float64, device=dev)
     if world > 1:
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        elapsed_max, rays_total = float(tm[0]), float(ts[1])
+        elapsed_max, rays_total, ranks_seen = float(tm[0]), float(ts[1]), int(round(float(ts[2])))
     else:
-        elapsed_max, rays_total = elapsed, float(agg["rays"])
+        elapsed_max, rays_total, ranks_seen = elapsed, float(agg["rays"]), 1
+    if ranks_seen != world:
+        raise SystemExit(f"all-reduce saw {ranks_seen} ranks, expected {world}")
 
     if rank == 0:
         names = KNAMES[algo]
         tf = lambda f, ms: f / max(ms, 1e-9) / 1e9                       # FLOP, ms -> TFLOP/s
-        ach = tf(agg[f"f{dom}"], agg[f"ms{dom}"])
+        ach = tf(agg["exec_flop"], agg["ms"])
+        q = pmc_quote(names[dom], args.workload, args.algo)
         roof = {"bound": "valu", "kernel": f"{names[dom]} ({KLABEL[dom]})", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
-                "traffic": measured_traffic(names[dom], args.workload, args.algo),
-                "flop_model": "algorithmic work of the reference's linear scans: 44 FLOP per ray-triangle test + 25 per "
-                              "ray-sphere test, every primitive per closest-hit ray, up to the first occluder per shadow ray",
-                "avg_launch_ms": agg[f"ms{dom}"] / max(1, agg[f"l{dom}"]),
+                "traffic": q.get("hbm_bytes_per_launch") if q else None,
+                "flop_model": (f"work the kernel executed, counted on the device: {F_NODE:.0f} FLOP per visited 4-wide node + 44 per exact "
+                               "triangle test + 25 per sphere test") if algo == "bvh" else
+                              ("packed-FP32 filter instructions the kernel executed (30 or 66 FLOP per lane, triangle pair and ray; "
+                               "packed FMA = 4 FLOP per lane), exact tests of survivors left out"),
+                "avg_launch_ms": agg["ms"] / max(1, agg["launches"]), "launches_per_step": agg["launches"] / args.steps,
                 "kernel_ms_per_step": {f"{names[k]} ({KLABEL[k]})": probe_ms[k] for k in range(4)},
                 "kernel_ms_note": "all classes: one untimed frame with every launch timed; the timed steps time the dominant class only",
-                "kernel_tflops": {f"{names[k]} ({KLABEL[k]})": tf(agg[f"f{k}"] / args.steps, probe_ms[k]) for k in range(3)}}
-        roof["lanes"] = int(st.lanes)
-        if st.lanes > 1:
+                "lanes": lanes, "limiter": limiter_of(q), "pmc": q,
+                "scan_equivalent": {"tflops": tf(agg["equiv_flop"], agg["ms"]),
+                                    "note": "FLOP the reference's linear scans would have spent on the same rays (44 per ray-triangle test, every "
+                                            "triangle per closest-hit ray, up to the first occluder per shadow ray) / the same kernel time: an "
+                                            "algorithm ratio, not a hardware fraction"}}
+        if lanes > 1:
             roof["lanes_note"] = ("the frame is traced on two concurrent streams (even / odd tiles); kernel times are per-launch "
                                   "HIP-event durations of overlapping launches and sum to more than ms_per_step")
-        if algo == "bvh":
-            xa = tf(agg[f"x{dom}"], agg[f"ms{dom}"])
-            roof["executed"] = {"achieved": xa, "frac": xa / PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                                "flop_model": f"{F_NODE:.0f} FLOP per visited node + 44 per exact triangle test + 25 per sphere test, "
-                                              "as counted by the kernels"}
-            roof["note"] = ("frac > 1: the hierarchy proves most of the reference's tests unnecessary and never executes them; "
-                            "`executed` prices only the work the kernel did. --algo brute runs the reference's full scans "
-                            "(VALU-bound, frac ~ 1).")
         res = {
             "metric": "Mrays/sec (primary+secondary)", "value": rays_total / elapsed_max / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "width": W, "height": H, "max_depth": depth, "triangles": fs.n_tri,
@@ -239,6 +383,8 @@ def main():
                        "rays_per_frame": rays_total / args.steps},
             "roofline": roof,
         }
+        if world == 1 and algo == "bvh" and not args.no_brute:
+            res["roofline_brute"] = brute_leg(fs, local_rank, step, st, args.workload)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(fs, W, H, depth, args.cpu_budget)
         print(json.dumps(res), flush=True)
@@ -246,7 +392,50 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def brute_leg(fs, device, step, st, workload, warmup=1, steps=2):
+    """The same frame by the reference's algorithm: index-order scans of every triangle (no chunk is skipped), every
+    launch timed with HIP events.  Returns the roofline of its dominant kernel class from executed instructions."""
+    from raytracer_amd.executor import HipExecutor
+    os.environ["HIPEXEC_NO_CULL"] = "1"
+    try:
+        exb = HipExecutor(fs, device=device)
+    finally:
+        os.environ.pop("HIPEXEC_NO_CULL", None)
+    try:
+        for _ in range(warmup):
+            step(False, exe=exb, a="scan")
+        ms = [0.0] * 4; launches = [0] * 4; flop = [0.0] * 3; equiv = [0.0] * 3; rays = 0; total_ms = 0.0
+        for _ in range(steps):
+            step(True, exe=exb, a="scan")
+            rays += st.rays; total_ms += st.total_ms
+            for k in range(4):
+                ms[k] += st.kernel_ms[k]; launches[k] += st.launches[k]
+            for k in range(3):
+                flop[k] += executed_flops_scan(st, k); equiv[k] += scan_equiv_flops(st, k, fs.n_sph)
+    finally:
+        exb.close()
+    names = KNAMES["scan"]
+    dom = max(range(3), key=lambda k: ms[k])
+    tf = lambda f, m: f / max(m, 1e-9) / 1e9
+    q = pmc_quote(names[dom], workload, "brute")
+    ach = tf(flop[dom], ms[dom])
+    return {"bound": "valu", "kernel": f"{names[dom]} ({KLABEL[dom]})", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": q.get("hbm_bytes_per_launch") if q else None,
+            "flop_model": "packed-FP32 filter instructions the kernel executed, from its own counters: per (wave, 128-triangle chunk) 64 pairs x 64 lanes "
+                          "x rays per lane x (3 packed mul + 6 or 15 packed FMA; packed FMA = 4 FLOP per lane); min/max/compare instructions "
+                          "and the exact tests of survivors carry no FLOP, so the fraction stays below the VALU utilisation",
+            "avg_launch_ms": ms[dom] / max(1, launches[dom]), "steps": steps, "warmup": warmup,
+            "ms_per_frame": total_ms / steps, "mrays_per_s": rays / max(total_ms, 1e-9) / 1e3,
+            "kernel_ms_per_frame": {f"{names[k]} ({KLABEL[k]})": ms[k] / steps for k in range(4)},
+            "kernel_frac": {f"{names[k]} ({KLABEL[k]})": tf(flop[k], ms[k]) / PEAK_FP32_VALU_TFLOPS for k in range(3)},
+            "limiter": limiter_of(q), "pmc": q,
+            "scan_equivalent": {"tflops": tf(equiv[dom], ms[dom]),
+                                "note": "44 FLOP per ray-triangle test of the reference's scalar code; the filter answers most tests with "
+                                        "fewer instructions, so this exceeds what the silicon executed"}}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
