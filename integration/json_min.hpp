@@ -1,7 +1,16 @@
-// json_min.hpp — small recursive-descent JSON reader (RFC 8259 subset sufficient for .scene files:
-// objects, arrays, strings with escapes, numbers, true/false/null).  Numbers are kept as double,
-// like the reference's JSON library does before they are narrowed (scene.cpp:24-134).
+// json_min.hpp — small recursive-descent JSON reader (RFC 8259: objects, arrays, strings with escapes,
+// numbers, true/false/null), sufficient for .scene files.
+//
+// Numbers follow the reference's JSON library (lib/json.h, nlohmann/json 2.1.1, get_number at :11259-11310)
+// because loadScene narrows them straight from its stored type (scene.cpp:53-57 `float x = i[0]`,
+// :97-99 `int x = i["center"][0]`): a token without fraction and exponent is stored as an unsigned or
+// signed 64-bit integer when it fits ("-0" is the integer 0, hence +0.0f), every other token as the
+// double strtod gives; f32() / i32() are the static_casts from that stored type.  A token whose value
+// is not finite (1e999) is rejected here (the reference stores null and then throws on conversion).
 #pragma once
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -15,9 +24,13 @@ namespace rt_hip {
 class Json {
 public:
     enum Kind { Null, Bool, Number, String, Array, Object };
+    enum NumKind { Float, Integer, Unsigned };
     Kind kind = Null;
+    NumKind num_kind = Float;
     bool b = false;
-    double num = 0.0;
+    double num = 0.0;             // the value as a double (exact for Float; rounded for 64-bit integers beyond 2^53)
+    int64_t i64 = 0;              // stored value of an Integer token
+    uint64_t u64 = 0;             // stored value of an Unsigned token
     std::string str;
     std::vector<Json> arr;
     std::vector<std::pair<std::string, Json>> obj;     // insertion order; lookups are linear (small objects)
@@ -44,13 +57,28 @@ public:
         if (kind != Number) throw std::runtime_error("json: number expected");
         return num;
     }
+    // `float x = value;` / `int x = value;` of the reference's library: static_cast from the stored type
+    float f32() const {
+        if (kind != Number) throw std::runtime_error("json: number expected");
+        return num_kind == Integer ? static_cast<float>(i64) : (num_kind == Unsigned ? static_cast<float>(u64) : static_cast<float>(num));
+    }
+    int32_t i32() const {
+        if (kind != Number) throw std::runtime_error("json: number expected");
+        if (num_kind == Integer) return static_cast<int32_t>(i64);
+        if (num_kind == Unsigned) return static_cast<int32_t>(u64);
+        // a double outside the int range is undefined in the reference's cast; x86-64 gives INT_MIN, kept here
+        if (!(num > -2147483649.0 && num < 2147483648.0)) return INT32_MIN;
+        return static_cast<int32_t>(num);
+    }
     const std::string &string() const {
         if (kind != String) throw std::runtime_error("json: string expected");
         return str;
     }
 
+    static constexpr int MAX_DEPTH = 256;      // nesting limit: a hostile file cannot overflow the stack
+
     static Json parse(const std::string &text) {
-        Parser p{text.c_str(), text.c_str() + text.size()};
+        Parser p{text.c_str(), text.c_str() + text.size(), 0};
         Json v = p.value();
         p.ws();
         if (p.cur != p.end) p.fail("trailing characters");
@@ -60,6 +88,7 @@ public:
 private:
     struct Parser {
         const char *cur, *end;
+        int depth;
         [[noreturn]] void fail(const char *what) const { throw std::runtime_error(std::string("json: ") + what); }
         void ws() { while (cur < end && (*cur == ' ' || *cur == '\t' || *cur == '\n' || *cur == '\r')) cur++; }
         bool eat(char c) { ws(); if (cur < end && *cur == c) { cur++; return true; } return false; }
@@ -115,9 +144,46 @@ private:
                 }
             }
         }
+        // number token: -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+        void number_token(Json &v) {
+            const char *start = cur;
+            bool neg = false, integral = true;
+            auto digit = [&]() { return cur < end && *cur >= '0' && *cur <= '9'; };
+            if (cur < end && *cur == '-') { neg = true; cur++; }
+            if (!digit()) fail("number expected");
+            if (*cur == '0') cur++; else while (digit()) cur++;
+            if (cur < end && *cur == '.') { integral = false; cur++; if (!digit()) fail("digit expected after '.'"); while (digit()) cur++; }
+            if (cur < end && (*cur == 'e' || *cur == 'E')) {
+                integral = false; cur++;
+                if (cur < end && (*cur == '+' || *cur == '-')) cur++;
+                if (!digit()) fail("digit expected in exponent");
+                while (digit()) cur++;
+            }
+            std::string tok(start, cur);
+            v.kind = Number; v.num_kind = Float;
+            if (integral) {
+                errno = 0;
+                char *stop = nullptr;
+                if (neg) {
+                    long long x = strtoll(tok.c_str(), &stop, 10);
+                    if (errno == 0 && *stop == 0) { v.num_kind = Integer; v.i64 = x; v.num = (double)x; return; }
+                } else {
+                    unsigned long long x = strtoull(tok.c_str(), &stop, 10);
+                    if (errno == 0 && *stop == 0) { v.num_kind = Unsigned; v.u64 = x; v.num = (double)x; return; }
+                }
+            }
+            v.num = strtod(tok.c_str(), nullptr);
+            if (!std::isfinite(v.num)) fail("number out of range");
+        }
         Json value() {
             ws();
             if (cur >= end) fail("unexpected end");
+            if (++depth > MAX_DEPTH) fail("nesting too deep");
+            Json v = value_at_depth();
+            depth--;
+            return v;
+        }
+        Json value_at_depth() {
             Json v;
             char c = *cur;
             if (c == '{') {
@@ -142,12 +208,7 @@ private:
             } else if (c == 't') { literal("true"); v.kind = Bool; v.b = true; }
             else if (c == 'f') { literal("false"); v.kind = Bool; v.b = false; }
             else if (c == 'n') { literal("null"); v.kind = Null; }
-            else {
-                char *stop = nullptr;
-                v.num = strtod(cur, &stop);
-                if (stop == cur || stop > end) fail("number expected");
-                cur = stop; v.kind = Number;
-            }
+            else number_token(v);
             return v;
         }
     };

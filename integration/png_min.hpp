@@ -1,7 +1,9 @@
 // png_min.hpp — PNG decoding to RGBA8 (rows top-down) and a plain RGB8 PNG writer, on zlib.
-// Role of lodepng::decode in tex_image::createImage (tex_image.h:25-31).  Supports the
-// non-interlaced colour types 0/2/3/4/6 at 8 or 16 bits per channel and palette/grey images at
-// 1/2/4 bits; anything else is reported as an error.
+// Role of lodepng::decode in tex_image::createImage (tex_image.h:25-31), whose results it reproduces byte for
+// byte: colour types 0/2/3/4/6 at every legal bit depth, tRNS keys compared at full sample width, 16-bit
+// samples reduced to their high byte, sub-byte grey scaled by 255/(2^depth - 1), Adam7 interlacing, a palette
+// index beyond the palette read as opaque black; chunk CRCs are verified and an unknown critical chunk, a bad
+// filter type, a colour type / depth pair the format does not allow or truncated data are errors.
 #pragma once
 #include <zlib.h>
 
@@ -42,6 +44,7 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
         uint32_t len = be32(&file[pos]);
         const uint8_t *type = &file[pos + 4], *body = &file[pos + 8];
         if (pos + 12 + (size_t)len > file.size()) fail("truncated chunk");
+        if ((uint32_t)crc32(0L, type, 4 + len) != be32(body + len)) fail("chunk checksum mismatch");
         if (!memcmp(type, "IHDR", 4)) {
             if (len < 13) fail("bad IHDR");
             W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
@@ -49,10 +52,11 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
         else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!memcmp(type, "IEND", 4)) end = true;
+        else if (!(type[0] & 0x20)) fail("unknown critical chunk");
         pos += 12 + (size_t)len;
     }
     if (W == 0 || H == 0 || ctype < 0) fail("missing IHDR");
-    if (interlace != 0) fail("interlaced PNG is not supported");
+    if (interlace > 1) fail("unknown interlace method");
     int channels;
     switch (ctype) {
     case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
@@ -60,17 +64,33 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
     default: fail("unknown colour type"); return {};
     }
     bool sub_byte = depth == 1 || depth == 2 || depth == 4;
-    if (!(depth == 8 || depth == 16 || (sub_byte && (ctype == 0 || ctype == 3)))) fail("unsupported bit depth");
-    size_t bits_pp = (size_t)channels * depth;
-    size_t stride = ((size_t)W * bits_pp + 7) / 8, bpp = (bits_pp + 7) / 8;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+    if (!((depth == 8) || (depth == 16 && ctype != 3) || (sub_byte && (ctype == 0 || ctype == 3)))) fail("unsupported bit depth");
+    const size_t bits_pp = (size_t)channels * depth, bpp = (bits_pp + 7) / 8;
+    // sub-images of the stream: the whole picture, or the seven Adam7 passes {x0, y0, dx, dy}
+    struct Pass { uint32_t x0, y0, dx, dy, w, h; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back({0, 0, 1, 1, W, H});
+    else {
+        static const uint32_t A7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+        for (const auto &a : A7) {
+            uint32_t w = W > a[0] ? (W - a[0] + a[2] - 1) / a[2] : 0, h = H > a[1] ? (H - a[1] + a[3] - 1) / a[3] : 0;
+            if (w && h) passes.push_back({a[0], a[1], a[2], a[3], w, h});
+        }
+    }
+    size_t raw_size = 0;
+    for (const Pass &p : passes) raw_size += (((size_t)p.w * bits_pp + 7) / 8 + 1) * p.h;
+    std::vector<uint8_t> raw(raw_size);
     uLongf out_len = (uLongf)raw.size();
     int zr = uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size());
     if (zr != Z_OK || out_len != raw.size()) fail("corrupt image data");
-    // undo the per-row filters in place
+    ImageRGBA8 img; img.width = W; img.height = H; img.rgba.resize((size_t)W * H * 4);
+    size_t pass_off = 0;
+    for (const Pass &ps : passes) {
+    const size_t stride = ((size_t)ps.w * bits_pp + 7) / 8;
+    // undo the per-row filters of this sub-image in place
     std::vector<uint8_t> prev(stride, 0);
-    for (uint32_t y = 0; y < H; y++) {
-        uint8_t *row = &raw[(stride + 1) * (size_t)y];
+    for (uint32_t y = 0; y < ps.h; y++) {
+        uint8_t *row = &raw[pass_off + (stride + 1) * (size_t)y];
         uint8_t ft = row[0];
         uint8_t *px = row + 1;
         for (size_t i = 0; i < stride; i++) {
@@ -85,7 +105,6 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
         }
         prev.assign(px, px + stride);
     }
-    ImageRGBA8 img; img.width = W; img.height = H; img.rgba.resize((size_t)W * H * 4);
     auto sample = [&](const uint8_t *px, size_t x, int ch) -> uint32_t {       // sample scaled to 8 bits
         if (depth == 8) return px[x * channels + ch];
         if (depth == 16) return px[(x * channels + ch) * 2];                   // high byte
@@ -93,10 +112,10 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
         uint32_t v = (px[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
         return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
     };
-    for (uint32_t y = 0; y < H; y++) {
-        const uint8_t *px = &raw[(stride + 1) * (size_t)y + 1];
-        uint8_t *dst = &img.rgba[(size_t)y * W * 4];
-        for (uint32_t x = 0; x < W; x++, dst += 4) {
+    for (uint32_t y = 0; y < ps.h; y++) {
+        const uint8_t *px = &raw[pass_off + (stride + 1) * (size_t)y + 1];
+        for (uint32_t x = 0; x < ps.w; x++) {
+            uint8_t *dst = &img.rgba[((size_t)(ps.y0 + y * ps.dy) * W + (ps.x0 + x * ps.dx)) * 4];
             switch (ctype) {
             case 0: {
                 uint32_t g = sample(px, x, 0);
@@ -123,7 +142,7 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
                 break;
             case 3: {
                 uint32_t i = sample(px, x, 0);
-                if ((size_t)i * 3 + 2 >= plte.size()) fail("palette index out of range");
+                if ((size_t)i * 3 + 2 >= plte.size()) { dst[0] = dst[1] = dst[2] = 0; dst[3] = 255; break; }   // as the reference's decoder does
                 dst[0] = plte[i * 3]; dst[1] = plte[i * 3 + 1]; dst[2] = plte[i * 3 + 2];
                 dst[3] = i < trns.size() ? trns[i] : 255;
                 break;
@@ -135,6 +154,8 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
                 for (int ch = 0; ch < 4; ch++) dst[ch] = (uint8_t)sample(px, x, ch);
             }
         }
+    }
+    pass_off += (stride + 1) * (size_t)ps.h;
     }
     return img;
 }

@@ -59,10 +59,10 @@ public:
             const Json &m = mats.at(i);
             float c[3]; vec3(m.need("diffusiveColor"), c);
             s.mat_color.insert(s.mat_color.end(), c, c + 3);
-            s.mat_kd.push_back((float)m.need("diffusiveFactor").number());
-            s.mat_ks.push_back((float)m.need("specularFactor").number());
-            s.mat_hard.push_back((float)m.need("specularHardness").number());
-            s.mat_kr.push_back((float)m.need("reflectionFactor").number());
+            s.mat_kd.push_back(m.need("diffusiveFactor").f32());
+            s.mat_ks.push_back(m.need("specularFactor").f32());
+            s.mat_hard.push_back(m.need("specularHardness").f32());
+            s.mat_kr.push_back(m.need("reflectionFactor").f32());
             const Json &ip = m.get("imagePath");
             if (!ip.is_null()) {
                 std::string p = ip.string();
@@ -72,8 +72,8 @@ public:
                 s.tex_offset.push_back(s.tex_rgba.size());
                 s.tex_w.push_back(img.width); s.tex_h.push_back(img.height);
                 s.tex_rgba.insert(s.tex_rgba.end(), img.rgba.begin(), img.rgba.end());
-                scale_x.push_back((float)m.need("scaleX").number());
-                scale_y.push_back((float)m.need("scaleY").number());
+                scale_x.push_back(m.need("scaleX").f32());
+                scale_y.push_back(m.need("scaleY").f32());
             } else {
                 s.mat_tex.push_back(-1); scale_x.push_back(1.0f); scale_y.push_back(1.0f);
             }
@@ -103,7 +103,7 @@ public:
             const Json &uv = f.get("uv");
             if (!uv.is_null()) {
                 float c[3][2];
-                for (int k = 0; k < 3; k++) { c[k][0] = (float)uv.at(k).at(0).number(); c[k][1] = (float)uv.at(k).at(1).number(); }
+                for (int k = 0; k < 3; k++) { c[k][0] = uv.at(k).at(0).f32(); c[k][1] = uv.at(k).at(1).f32(); }
                 float *t = &s.tri_uv[6 * i];
                 t[0] = c[0][0]; t[1] = c[0][1];
                 t[2] = c[1][0] - c[0][0]; t[3] = c[1][1] - c[0][1];
@@ -124,8 +124,8 @@ public:
         const Json &sph = doc.get("spheres");
         for (size_t i = 0; i < sph.size(); i++) {
             const Json &sp = sph.at(i);
-            for (int k = 0; k < 3; k++) s.sph_center.push_back((float)(int)sp.need("center").at(k).number());
-            s.sph_radius.push_back((float)sp.need("radius").number());
+            for (int k = 0; k < 3; k++) s.sph_center.push_back((float)sp.need("center").at(k).i32());
+            s.sph_radius.push_back(sp.need("radius").f32());
             const Json &mi = sp.get("material");
             int mat = mi.is_null() ? -1 : (int)mi.number();
             if (mat >= (int)mats.size()) throw std::runtime_error("scene: sphere material index out of range");
@@ -134,9 +134,9 @@ public:
         const Json &lamps = doc.get("lamps");
         for (size_t i = 0; i < lamps.size(); i++) {
             const Json &lp = lamps.at(i);
-            for (int k = 0; k < 3; k++) s.lamp_pos.push_back((float)(int)lp.need("pos").at(k).number());
-            s.lamp_intensity.push_back((float)lp.need("intensity").number());
-            s.lamp_distance.push_back((float)lp.need("distance").number());
+            for (int k = 0; k < 3; k++) s.lamp_pos.push_back((float)lp.need("pos").at(k).i32());
+            s.lamp_intensity.push_back(lp.need("intensity").f32());
+            s.lamp_distance.push_back(lp.need("distance").f32());
         }
         vec3(doc.need("translate"), s.cam_pos);
         const Json &tr = doc.need("transform");
@@ -192,7 +192,7 @@ public:
 
 private:
     static void vec3(const Json &a, float *out) {
-        for (int k = 0; k < 3; k++) out[k] = (float)a.at(k).number();
+        for (int k = 0; k < 3; k++) out[k] = a.at(k).f32();
     }
 };
 

@@ -3,8 +3,8 @@
 CPU part: the loader's flattened arrays equal the Python loader's (raytracer_amd/scene.py,
 itself checked against hand-computed values in test_scene_loader.py) bit for bit on scenes that
 exercise textures, null materials, faces without UVs, missing world block and fractional
-sphere / lamp coordinates.  GPU part: a frame rendered by the CLI equals the frame rendered
-through the Python binding."""
+sphere / lamp coordinates.  GPU part: a frame rendered by the CLI matches the oracle's frame of the
+same scene file (hit ids exact, RGB8 gate) and equals the frame rendered through the Python binding."""
 import os
 import struct
 import subprocess
@@ -106,7 +106,7 @@ def test_png_decoder_colour_types(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,depth", [("cl", 0), ("cpu", 2)])
-def test_cli_frame_equals_binding(tmp_path, mode, depth):
+def test_cli_frame_matches_oracle_and_binding(tmp_path, mode, depth):
     needs_cli()
     from raytracer_amd import _abi
     from raytracer_amd.executor import HipExecutor
@@ -122,6 +122,12 @@ def test_cli_frame_equals_binding(tmp_path, mode, depth):
     assert raw.startswith(head)
     img = np.frombuffer(raw[len(head):], np.float32).reshape(H, W, 3)
     m = _abi.HIPEXEC_MODE_CL if mode == "cl" else _abi.HIPEXEC_MODE_CPU
+    # the CLI's frame (C++ loader -> C ABI -> file) against the oracle on the scene the Python loader reads
+    from oracle.binding import Oracle
+    from tests.util import assert_image_parity
+    oref = Oracle(load_scene(path)).render(W, H, mode=m, max_depth=depth, tone=1, n_threads=8)
+    assert np.array_equal(np.fromfile(ids, np.int32).reshape(oref["ids"].shape), oref["ids"])
+    assert_image_parity(img, oref["rgb"], min_frac=1.0)
     with HipExecutor(load_scene(path), device=0) as ex:
         ref = ex.render(W, H, mode=m, max_depth=depth, tone=True)
     assert np.array_equal(img.view(np.int32), ref["rgb"].view(np.int32))

@@ -1,0 +1,106 @@
+"""File-format readers against the REFERENCE's own third-party code.
+
+The reference decodes textures with lib/lodepng.cpp (tex_image.h:25-31) and parses scenes with lib/json.h
+(scene.cpp:20-22, number conversions :53-57, :97-99).  Both compile unmodified in the build container
+(`make -C oracle ref`); tests/golden/ref_codec/ holds input files and what those two libraries made of them
+(generator: tests/golden/make_ref_codec_golden.py).  Here integration/png_min.hpp and json_min.hpp must give
+the same bytes: RGBA8 pixels, accept/reject verdicts, float bit patterns and int truncations.  Where the
+reference build exists, the committed fixtures are additionally re-derived from it."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "ref_codec")
+REF_CODEC = os.path.join(ROOT, "oracle", "_ref", "ref_codec")
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("codec") / "codec_probe")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-ffp-contract=off", "-I", os.path.join(ROOT, "integration"),
+                    os.path.join(ROOT, "tests", "cpp", "codec_probe.cpp"), "-lz", "-o", out], check=True)
+    return out
+
+
+@pytest.fixture(scope="module")
+def expected():
+    return dict(np.load(os.path.join(GOLD, "expected.npz")))
+
+
+def _png_names():
+    return sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".png"))
+
+
+def _decode(tool, path, tmp):
+    subprocess.run([tool, "png", path, tmp], check=True, capture_output=True)
+    raw = open(tmp, "rb").read()
+    err, w, h = struct.unpack("<III", raw[:12])
+    return err, w, h, np.frombuffer(raw[12:], np.uint8)
+
+
+def test_fixture_set_covers_the_format(expected):
+    names = _png_names()
+    assert len(names) >= 100
+    for ctype, depths in ((0, (1, 2, 4, 8, 16)), (2, (8, 16)), (3, (1, 2, 4, 8)), (4, (8, 16)), (6, (8, 16))):
+        for d in depths:
+            for i in (0, 1):
+                assert any(n.startswith(f"c{ctype}_d{d}_") and n.endswith(f"_i{i}") for n in names)
+    assert sum(int(expected[f"png/{n}/err"]) != 0 for n in names) >= 6
+
+
+@pytest.mark.parametrize("name", _png_names())
+def test_png_decoder_equals_reference_lodepng(probe, expected, tmp_path, name):
+    err, w, h, rgba = _decode(probe, os.path.join(GOLD, name + ".png"), str(tmp_path / "o.bin"))
+    ref_err = int(expected[f"png/{name}/err"])
+    assert (err != 0) == (ref_err != 0), f"reference error code {ref_err}, this decoder {'rejects' if err else 'accepts'}"
+    if ref_err == 0:
+        assert [w, h] == list(expected[f"png/{name}/size"])
+        assert np.array_equal(rgba, expected[f"png/{name}/rgba"])
+
+
+def test_json_numbers_equal_reference_library(probe, expected, tmp_path):
+    out = str(tmp_path / "n.bin")
+    subprocess.run([probe, "json", os.path.join(GOLD, "numbers.json"), out], check=True, capture_output=True)
+    raw = open(out, "rb").read()
+    n = struct.unpack("<I", raw[:4])[0]
+    fl = np.frombuffer(raw, np.float32, n, 4)
+    m = struct.unpack("<I", raw[4 + 4 * n:8 + 4 * n])[0]
+    iv = np.frombuffer(raw, np.int32, m, 8 + 4 * n)
+    ifl = np.frombuffer(raw, np.float32, m, 8 + 4 * n + 4 * m)
+    assert np.array_equal(fl.view(np.uint32), expected["json/floats"].view(np.uint32)), \
+        np.nonzero(fl.view(np.uint32) != expected["json/floats"].view(np.uint32))
+    assert np.array_equal(iv, expected["json/ints"])
+    assert np.array_equal(ifl.view(np.uint32), expected["json/ints_as_float"].view(np.uint32))
+    # the quirk the loader depends on: sphere centres and lamp positions truncate toward zero (scene.cpp:97-99)
+    doc = open(os.path.join(GOLD, "numbers.json")).read()
+    toks = doc.split('"ints": [')[1].split("]")[0].split(", ")
+    got = dict(zip(toks, iv))
+    assert got["0.7"] == 0 and got["-3.9"] == -3 and got["-0.9"] == 0 and got["2.5"] == 2 and got["-2.5"] == -2
+
+
+def test_json_reader_rejects_what_the_grammar_rejects(probe, tmp_path):
+    for bad in ('{"floats": [01], "ints": []}', '{"floats": [.5], "ints": []}', '{"floats": [1.], "ints": []}',
+                '{"floats": [+1], "ints": []}', '{"floats": [1e], "ints": []}', '{"floats": [0x10], "ints": []}',
+                '{"floats": [nan], "ints": []}', "[" * 100000):
+        p = tmp_path / "bad.json"
+        p.write_text(bad)
+        r = subprocess.run([probe, "json", str(p), str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 1 and "json" in r.stderr, bad[:40]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CODEC), reason="reference build (oracle/_ref) only exists in the build container")
+def test_committed_fixtures_are_what_the_reference_build_says(expected, tmp_path):
+    tmp = str(tmp_path / "o.bin")
+    for name in _png_names():
+        err, w, h, rgba = _decode(REF_CODEC, os.path.join(GOLD, name + ".png"), tmp)
+        assert err == int(expected[f"png/{name}/err"]), name
+        if err == 0:
+            assert [w, h] == list(expected[f"png/{name}/size"]) and np.array_equal(rgba, expected[f"png/{name}/rgba"]), name
+    subprocess.run([REF_CODEC, "json", os.path.join(GOLD, "numbers.json"), tmp], check=True)
+    raw = open(tmp, "rb").read()
+    n = struct.unpack("<I", raw[:4])[0]
+    assert np.array_equal(np.frombuffer(raw, np.uint32, n, 4), expected["json/floats"].view(np.uint32))
