@@ -130,7 +130,7 @@ typedef struct hipexec_render_cfg {
  * colours; they differ in which tests they can prove unnecessary. */
 enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };
 
-#define HIPEXEC_ABI_VERSION 2
+#define HIPEXEC_ABI_VERSION 3
 
 /* Kernel classes reported in hipexec_stats. */
 enum {
@@ -239,6 +239,18 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg,
 typedef void (*hipexec_rows_cb)(void *user, int32_t first_row, int32_t row_count);
 int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int32_t rows_per_step,
                                float *out_rgb, hipexec_rows_cb on_rows, void *user, hipexec_stats *stats);
+
+/*
+ * Replaces renderSubBlockCl (ray_tracer_cl.cpp:59-105): renders the pixels [x, x+w) x [y, y+h) of the frame cfg
+ * describes (cfg->width / height are the reference's fullWidth / fullHeight, :66-72) into out_rgb, the WHOLE frame's
+ * [height][width][3] image; pixels outside the rectangle are left untouched, and the part of the rectangle outside
+ * the frame is dropped like image_bitmap::setPixel drops it (image_bitmap.h:36-49).  Camera rays are made on the
+ * device from the pixel coordinates (the expressions of :80-92), traced, toned (:94-104) and only the rectangle
+ * crosses PCIe.  The pixels equal those hipexec_render gives for the same cfg.  out_ids (optional) is the whole
+ * frame's [height][width][spp] array.  Whole frames only (tile_first 0, tile_step 1).
+ */
+int hipexec_render_rect(hipexec_t *h, const hipexec_render_cfg *cfg, int32_t x, int32_t y, int32_t w, int32_t hgt,
+                        float *out_rgb, int32_t *out_ids, hipexec_stats *stats);
 
 /*
  * Same work as hipexec_render but asynchronous and device-resident: results stay in device

@@ -15,7 +15,7 @@
 #include "ray_tracer_cl.h"
 #endif
 
-#include <cmath>
+#include <algorithm>
 #include <iostream>
 #include <memory>
 #include <stdexcept>
@@ -64,42 +64,30 @@ void renderSceneCl(image_bitmap &outImg, const Scene &scene)
                    "hipexec_render");
 }
 
-// ray_tracer_cl.cpp:59-105: rays of one sub-block are generated here exactly as the reference
-// does (so a caller that renders block-wise gets the same pixels), traced as a batch, toned.
+// ray_tracer_cl.cpp:59-105.  One call: the executor makes the block's camera rays on the device from the pixel
+// coordinates, traces and tones them and copies only the block back, straight into the image's rows.  The pixels are
+// those renderSceneCl writes for the same frame size.  (An image whose size differs from fullWidth x fullHeight is
+// served through a frame-sized staging image and setPixel, which drops what falls outside, image_bitmap.h:36-49.)
 void renderSubBlockCl(image_bitmap &outImg, const Scene &scene, std::shared_ptr<OpenClExecutor> clExecutor,
                       int x, int y, int w, int h, int fullWidth, int fullHeight)
 {
-    auto width = fullWidth;
-    auto height = fullHeight;
-    float camHeight = 0.5;
-    float camWidth = static_cast<float>(width) * (camHeight / static_cast<float>(height));
-    float camDist = 1.0;
-    float dh = camHeight / static_cast<float>(height);
-    float dw = camWidth / static_cast<float>(width);
-    std::vector<glm::vec3> tracedColors;
-    std::vector<RayData> raysToTrace;
-    tracedColors.reserve((unsigned long)(w * h));
-    raysToTrace.reserve((unsigned long)(w * h));
-    for (int i = 0; i < h; i++) {
-        for (int j = 0; j < w; j++) {
-            float rayX = -(camWidth / 2) + (j + x) * dw;
-            float rayY = -(camHeight / 2) + (i + y) * dh;
-            glm::vec3 rayCamDir = glm::vec3(rayX, rayY, -camDist);
-            glm::vec3 rayWorldDir = glm::normalize(rayCamDir * scene.camMat);
-            tracedColors.push_back(glm::vec3(0.0f, 0.0f, 0.0f));
-            raysToTrace.push_back(RayData(scene.camPos.x, scene.camPos.y, scene.camPos.z,
-                                          rayWorldDir.x, rayWorldDir.y, rayWorldDir.z));
-        }
+    (void)scene;
+    hipexec_render_cfg cfg{};
+    cfg.width = fullWidth; cfg.height = fullHeight;
+    cfg.mode = HIPEXEC_MODE_CL; cfg.max_depth = 0; cfg.tone = 1;
+    cfg.tile_first = 0; cfg.tile_step = 1; cfg.flags = 0;
+    if (outImg.getWidth() == fullWidth && outImg.getHeight() == fullHeight) {
+        checkHipResult(hipexec_render_rect(clExecutor->handle(), &cfg, x, y, w, h, static_cast<float *>(outImg.getRawData()),
+                                           nullptr, nullptr), "hipexec_render_rect");
+        return;
     }
-    traceRaysCl(scene, clExecutor, raysToTrace, tracedColors, 0);
-    int k = 0;
-    for (int i = 0; i < h; i++) {
-        for (int j = 0; j < w; j++) {
-            outImg.setPixel(j + x, i + y, powf(tracedColors[k].x / 2.2f, 0.3f), powf(tracedColors[k].y / 2.2f, 0.3f),
-                            powf(tracedColors[k].z / 2.2f, 0.3f));
-            k++;
+    std::vector<float> frame((size_t)fullWidth * (size_t)fullHeight * 3);
+    checkHipResult(hipexec_render_rect(clExecutor->handle(), &cfg, x, y, w, h, frame.data(), nullptr, nullptr), "hipexec_render_rect");
+    for (int py = std::max(0, y); py < std::min(fullHeight, y + h); py++)
+        for (int px = std::max(0, x); px < std::min(fullWidth, x + w); px++) {
+            const float *c = &frame[((size_t)py * fullWidth + px) * 3];
+            outImg.setPixel(px, py, c[0], c[1], c[2]);
         }
-    }
 }
 
 // ray_tracer_cl.cpp:108-178: outColors[i] is accumulated into; depth is accepted and ignored (:114)

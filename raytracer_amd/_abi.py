@@ -17,7 +17,7 @@ HIPEXEC_FLAG_BVH = 4
 HIPEXEC_FLAG_BILINEAR = 8
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATIC_MAX_RAYS = 1 << 18
 
 _fp = C.POINTER(C.c_float)
@@ -104,6 +104,8 @@ PROTOTYPES = {
     "hipexec_render": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "hipexec_render_progressive": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.POINTER(Stats)]),
+    "hipexec_render_rect": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                            C.POINTER(Stats)]),
     "hipexec_render_device": (C.c_int, [C.c_void_p, C.POINTER(RenderCfg), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "hipexec_sync": (C.c_int, [C.c_void_p]),
     "hipexec_closest_hits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),

@@ -179,7 +179,8 @@ struct hipexec {
     // Second lane: an executor of its own (stream, work buffers, counters) on the same scene.  A frame
     // is split into even and odd tiles that the two lanes trace concurrently, so that the thinly
     // populated tail of one lane's kernels (a few very long rays) overlaps the other lane's work.
-    int win_lo = 0, win_hi = INT_MAX;         // window into the call's tile list (progressive rendering)
+    int win_lo = 0, win_hi = INT_MAX;         // window into the call's tile list (progressive rendering, sub-rectangles)
+    int rect[4] = {0, 0, INT_MAX, INT_MAX};   // pixel window x0, y0, x1, y1 of the call (hipexec_render_rect), clipped to the frame when used
     std::vector<hipexec *> helpers;           // further lanes of this executor (own streams, buffers, counters; no scene memory)
     bool is_helper = false;
     LaneWorker *worker = nullptr;             // host thread of a helper lane
@@ -894,7 +895,11 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
     int n_all = std::min(n_tiles_of(c), h->win_hi);
     const int first = h->win_lo + sub;
     int n_tiles = n_all > first ? (n_all - first + n_sub - 1) / n_sub : 0;
-    int nbx = (c->width + 7) / 8;
+    const int cx0 = std::max(0, h->rect[0]), cy0 = std::max(0, h->rect[1]);
+    const int cx1 = std::min(c->width, h->rect[2]), cy1 = std::min(c->height, h->rect[3]);
+    if (cx0 >= cx1 || cy0 >= cy1) return HIPEXEC_OK;
+    const int x_blk0 = cx0 / 8;
+    int nbx = (cx1 + 7) / 8 - x_blk0;
     int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : c->max_depth;
     // tiles per batch, bounded by the shadow queue
     uint64_t samples_per_tile = (uint64_t)nbx * 64 * SPP;
@@ -908,6 +913,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         F.tile_first = c->tile_first + F.out_first * c->tile_step;
         F.n_tiles = std::min(tiles_per_batch, n_tiles - t0);
         F.nbx = nbx; F.n_slots = (uint32_t)F.n_tiles * (uint32_t)nbx * 64u; F.spp = SPP;
+        F.x_blk0 = x_blk0; F.out_w = cx1 - cx0; F.cx0 = cx0; F.cx1 = cx1; F.cy0 = cy0; F.cy1 = cy1;
         uint64_t n0 = (uint64_t)F.n_slots * SPP;
         if (n0 > 0xfffffff0ull) return fail(HIPEXEC_E_LIMIT, "batch of %llu samples exceeds 32-bit indexing", (unsigned long long)n0);
         CHK(reserve_trace_buffers(h, n0, depth + 1));
@@ -922,9 +928,11 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
             LAUNCH(HIPEXEC_K_PRIMARY, (k_primary<MODE>), blocks_for(F.n_slots), S, F, h->rayA.as<float4>(), h->hit0.as<float4>(), h->d_cnt64);
         }
         int rows = 0;
-        for (int k = 0; k < F.n_tiles; k++)
-            rows += std::max(0, std::min(HIPEXEC_TILE_ROWS, c->height - (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS));
-        uint64_t prim = (uint64_t)rows * c->width * SPP;
+        for (int k = 0; k < F.n_tiles; k++) {
+            const int ty = (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS;
+            rows += std::max(0, std::min(ty + HIPEXEC_TILE_ROWS, cy1) - std::max(ty, cy0));
+        }
+        uint64_t prim = (uint64_t)rows * (uint64_t)(cx1 - cx0) * SPP;
         h->acc.rays_primary += prim;
         h->acc.tests_tri_primary += prim * S.n_tri;
         h->acc.tests_tri_closest += prim * S.n_tri;
@@ -963,6 +971,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     for (int k = 1; k < L; k++) {
         hipexec *g = h->helpers[(size_t)k - 1];
         g->win_lo = h->win_lo; g->win_hi = h->win_hi;
+        for (int q = 0; q < 4; q++) g->rect[q] = h->rect[q];
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
         g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
         g->worker->submit([&, g, k]() {
@@ -1272,6 +1281,48 @@ int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int3
     }
     h->win_lo = 0; h->win_hi = INT_MAX;
     if (rc == HIPEXEC_OK && stats) *stats = total;
+    return rc;
+}
+
+int hipexec_render_rect(hipexec_t *h, const hipexec_render_cfg *cfg, int32_t x, int32_t y, int32_t w, int32_t hgt,
+                        float *out_rgb, int32_t *out_ids, hipexec_stats *stats)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    CHK(validate_cfg(cfg));
+    if (!out_rgb) return fail(HIPEXEC_E_INVALID, "out_rgb is NULL");
+    if (cfg->tile_first != 0 || cfg->tile_step != 1) return fail(HIPEXEC_E_INVALID, "a rectangle is a window of the whole frame (tile_first 0, tile_step 1)");
+    if (w < 0 || hgt < 0) return fail(HIPEXEC_E_INVALID, "rectangle size %dx%d is negative", w, hgt);
+    if (stats) memset(stats, 0, sizeof *stats);
+    // pixels outside the frame are dropped, like image_bitmap::setPixel does (image_bitmap.h:36-49)
+    const int x0 = std::max(0, x), y0 = std::max(0, y);
+    const int x1 = (int)std::min<int64_t>(cfg->width, (int64_t)x + w), y1 = (int)std::min<int64_t>(cfg->height, (int64_t)y + hgt);
+    if (x0 >= x1 || y0 >= y1) return HIPEXEC_OK;
+    const int spp = cfg->mode == HIPEXEC_MODE_CL ? 1 : 4;
+    const int t_lo = y0 / HIPEXEC_TILE_ROWS, t_hi = (y1 + HIPEXEC_TILE_ROWS - 1) / HIPEXEC_TILE_ROWS;
+    const size_t rw = (size_t)(x1 - x0), rows_all = (size_t)t_hi * HIPEXEC_TILE_ROWS;      // output rows are addressed by frame row
+    HIPCHK(hipSetDevice(h->device));
+    CHK(h->out_rgba.reserve(rows_all * rw * 16));
+    if (out_ids) CHK(h->out_ids.reserve(rows_all * rw * 4 * spp));
+    CHK(h->stage_out.reserve((size_t)(y1 - y0) * rw * 12));
+    h->win_lo = t_lo; h->win_hi = t_hi;
+    h->rect[0] = x0; h->rect[1] = y0; h->rect[2] = x1; h->rect[3] = y1;
+    int rc = [&]() -> int {
+        CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
+        int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
+        if (r != HIPEXEC_OK) { h->call_open = false; return r; }
+        const size_t n_px = (size_t)(y1 - y0) * rw;
+        LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>() + (size_t)y0 * rw, n_px, h->stage_out.as<float>());
+        CHK(call_end(h, stats));
+        HIPCHK(hipMemcpy2D(out_rgb + ((size_t)y0 * cfg->width + x0) * 3, (size_t)cfg->width * 12, h->stage_out.p, rw * 12, rw * 12,
+                           (size_t)(y1 - y0), hipMemcpyDeviceToHost));
+        if (out_ids)
+            HIPCHK(hipMemcpy2D(out_ids + ((size_t)y0 * cfg->width + x0) * spp, (size_t)cfg->width * 4 * spp,
+                               h->out_ids.as<int32_t>() + (size_t)y0 * rw * spp, rw * 4 * spp, rw * 4 * spp, (size_t)(y1 - y0),
+                               hipMemcpyDeviceToHost));
+        return HIPEXEC_OK;
+    }();
+    h->win_lo = 0; h->win_hi = INT_MAX;
+    h->rect[0] = 0; h->rect[1] = 0; h->rect[2] = INT_MAX; h->rect[3] = INT_MAX;
     return rc;
 }
 

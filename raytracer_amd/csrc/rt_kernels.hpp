@@ -25,9 +25,13 @@ struct Frame {
     int W, H;              // full frame
     int tile_first, tile_step, n_tiles;
     int out_first, out_step;   // tile k of this call is stored as tile out_first + k * out_step of the output buffer
-    int nbx;               // 8x8 blocks per tile row = ceil(W/8)
+    int nbx;               // 8x8 blocks per tile row of this call
     uint32_t n_slots;      // n_tiles * nbx * 64 pixel slots (one thread each)
     int spp;
+    // Window of the frame this call renders: pixels [cx0, cx1) x [cy0, cy1) (the whole frame, or the sub-rectangle of
+    // a block-wise caller, ray_tracer_cl.cpp:59-105).  Block column 0 of the call starts at pixel x_blk0 * 8; the
+    // output buffer holds out_w pixels per row, its column 0 being pixel cx0.
+    int x_blk0, out_w, cx0, cx1, cy0, cy1;
 };
 
 struct RayRec { float4 a, b; };   // a = {o.xyz, d.x}  b = {d.y, d.z, sample index bits, lamp index bits}
@@ -344,11 +348,11 @@ DEV float filter_gen_one(const PairGen &P, int h, const RayF &r) {
 DEV bool slot_to_pixel(const Frame &F, uint32_t slot, int &x, int &y, int &lrow) {
     uint32_t blk = slot >> 6, lane = slot & 63;
     int k = (int)(blk / (uint32_t)F.nbx), bx = (int)(blk % (uint32_t)F.nbx);
-    x = bx * 8 + (int)(lane & 7);
+    x = (F.x_blk0 + bx) * 8 + (int)(lane & 7);
     int ly = (int)(lane >> 3);
     lrow = (F.out_first + k * F.out_step) * HIPEXEC_TILE_ROWS + ly;
     y = (F.tile_first + k * F.tile_step) * HIPEXEC_TILE_ROWS + ly;
-    return slot < F.n_slots && x < F.W && y < F.H;
+    return slot < F.n_slots && x >= F.cx0 && x < F.cx1 && y >= F.cy0 && y < F.cy1;
 }
 
 // Sample index of sub-sample r of pixel slot `slot` (slots: 64 per 8x8-pixel tile, row-major inside the tile).
@@ -993,11 +997,11 @@ __global__ __launch_bounds__(256) void k_resolve(Frame F, const float4 *__restri
         uint32_t s = sample_index<SPP>(F, slot, r);
         f3 t = fold_levels(local, level_stride, n_levels, s);
         c = (r == 0) ? t : (c + t);
-        if (out_ids) out_ids[((size_t)lrow * F.W + x) * SPP + r] = __float_as_int(hits0[s].w);
+        if (out_ids) out_ids[((size_t)lrow * F.out_w + (x - F.cx0)) * SPP + r] = __float_as_int(hits0[s].w);
     }
     if (MODE == HIPEXEC_MODE_CPU) c = c / 4.0f;
     if (tone) c = mk(pow_cr(c.x / 2.2f, 0.3f), pow_cr(c.y / 2.2f, 0.3f), pow_cr(c.z / 2.2f, 0.3f));
-    out_rgba[(size_t)lrow * F.W + x] = make_float4(c.x, c.y, c.z, 1.0f);
+    out_rgba[(size_t)lrow * F.out_w + (x - F.cx0)] = make_float4(c.x, c.y, c.z, 1.0f);
 }
 
 // batch variant for hipexec_trace_rays: colours3[i] += traced colour

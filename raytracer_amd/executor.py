@@ -102,6 +102,16 @@ class HipExecutor:
                                              ids.ctypes.data if ids is not None else None, C.byref(st)))
         return {"rgb": rgb, "ids": ids, "stats": st}
 
+    def render_rect(self, width, height, x, y, w, h, out, mode=HIPEXEC_MODE_CPU, max_depth=0, tone=True, ids=None, algo=None):
+        """Render the pixels [x, x+w) x [y, y+h) of the width x height frame into `out` ([height][width][3] float32, the
+        whole frame's image; the rest is left untouched).  -> Stats"""
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (height, width, 3)
+        st = _abi.Stats()
+        cfg = self._cfg(width, height, mode, max_depth, tone, 0, 1, False, algo)
+        self._check(self._lib.hipexec_render_rect(self._h, C.byref(cfg), int(x), int(y), int(w), int(h), out.ctypes.data,
+                                                  ids.ctypes.data if ids is not None else None, C.byref(st)))
+        return st
+
     def render_progressive(self, width, height, rows_per_step=48, on_rows=None, mode=HIPEXEC_MODE_CPU, max_depth=0,
                            tone=True, out=None, algo=None):
         """Render to host memory in steps of `rows_per_step` rows; `on_rows(first_row, row_count)` is called

@@ -40,10 +40,13 @@ def dot_f32(a, b):
 
 
 def normalize_f32(v):
-    """glm::normalize: v * (1 / sqrt(dot(v,v))), each step rounded to float32."""
+    """glm::normalize: v * (1 / sqrt(dot(v,v))), each step rounded to float32.  A zero vector (the cross product of a
+    zero-area triangle's edges, scene.cpp:91) gives 0 * inf = NaN exactly as the reference's loader stores it; such a
+    triangle has det = 0 for every ray and is never hit, so that normal is never read by the tracer."""
     v = _f32(v)
-    inv = (f32(1.0) / np.sqrt(dot_f32(v, v))).astype(np.float32)
-    return (v * inv[..., None]).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = (f32(1.0) / np.sqrt(dot_f32(v, v))).astype(np.float32)
+        return (v * inv[..., None]).astype(np.float32)
 
 
 @dataclass

@@ -42,14 +42,14 @@ static void loadScene(Scene &s, const char *path)
     }
     auto mat = [&](int idx) { return idx >= 0 ? s.materials[idx] : std::make_shared<Material>(); };   // scene.cpp:87-89
     for (size_t i = 0; i < nt; i++) {
-        auto t = std::make_shared<Triangle>();
-        t->p = v3(tp, i); t->e1 = v3(te1, i); t->e2 = v3(te2, i); t->norm = v3(tn, i);
-        t->uvStart = glm::vec2(tuv[6 * i], tuv[6 * i + 1]); t->uvU = glm::vec2(tuv[6 * i + 2], tuv[6 * i + 3]);
-        t->uvV = glm::vec2(tuv[6 * i + 4], tuv[6 * i + 5]); t->material = mat(tm[i]);
+        // the construction of scene.cpp:90-93
+        std::shared_ptr<Triangle> t(new Triangle(v3(tp, i), v3(te1, i), v3(te2, i), glm::vec2(tuv[6 * i], tuv[6 * i + 1]),
+                                                 glm::vec2(tuv[6 * i + 2], tuv[6 * i + 3]), glm::vec2(tuv[6 * i + 4], tuv[6 * i + 5]),
+                                                 v3(tn, i), mat(tm[i])));
         s.triangles.push_back(t);
     }
-    for (size_t i = 0; i < ns; i++) { auto p = std::make_shared<Sphere>(); p->center = v3(sc, i); p->radius = sr[i]; p->material = mat(sm[i]); s.spheres.push_back(p); }
-    for (size_t i = 0; i < nl; i++) { auto p = std::make_shared<Lamp>(); p->pos = v3(lp, i); p->intensity = li[i]; p->distance = ld[i]; s.lamps.push_back(p); }
+    for (size_t i = 0; i < ns; i++) s.spheres.push_back(std::shared_ptr<Sphere>(new Sphere(v3(sc, i), sr[i], mat(sm[i]))));      // scene.cpp:107
+    for (size_t i = 0; i < nl; i++) s.lamps.push_back(std::shared_ptr<Lamp>(new Lamp(v3(lp, i), li[i], ld[i])));                  // scene.cpp:117
     s.camPos = v3(cam, 0);
     for (int i = 0; i < 3; i++) s.camMat[i] = glm::vec3(cm[3 * i], cm[3 * i + 1], cm[3 * i + 2]);
     s.worldHorizonColor = v3(hz, 0); s.worldAmbientColor = v3(am, 0);

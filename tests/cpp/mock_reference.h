@@ -31,9 +31,14 @@ inline vec3 operator*(const vec3 &v, const mat3 &m) { return vec3(dot(m[0], v), 
 class tex_image {
 public:
     std::vector<unsigned char> data; unsigned w = 0, h = 0;
+    float scaleX = 1.0f, scaleY = 1.0f;
     std::vector<unsigned char> *getRawData() { return &data; }
-    unsigned getWidth() const { return w; }
-    unsigned getHeight() const { return h; }
+    unsigned int getWidth() const { return w; }
+    unsigned int getHeight() const { return h; }
+    float getScaleX() const { return scaleX; }
+    void setScaleX(float v) { scaleX = v; }
+    float getScaleY() const { return scaleY; }
+    void setScaleY(float v) { scaleY = v; }
 };
 
 class image_bitmap {
@@ -52,18 +57,36 @@ public:
 
 class OpenClExecutor;
 
+// members, their order and the constructor signatures follow scene.h:21-140 (every member the reference has, including
+// the two refraction fields it never reads), so a drift in a name or an argument order fails to compile here too
 struct Material {
     glm::vec3 color; std::shared_ptr<tex_image> texImage;
-    float diffusiveFactor = 0, specularFactor = 0, specularHardness = 0, reflectionFactor = 0;
-    bool textured = false;
+    float diffusiveFactor, specularFactor, specularHardness, reflectionFactor, refractionFactor, refractionHardness;
+    bool textured;
+    Material(const glm::vec3 &c = glm::vec3(0.0f, 0.0f, 0.0f), const std::shared_ptr<tex_image> &ti = std::shared_ptr<tex_image>(),
+             float kd = 0.0f, float ks = 0.0f, float hard = 0.0f, float kr = 0.0f, float kt = 0.0f, float th = 0.0f, bool tex = false)
+        : color(c), texImage(ti), diffusiveFactor(kd), specularFactor(ks), specularHardness(hard), reflectionFactor(kr),
+          refractionFactor(kt), refractionHardness(th), textured(tex) {}
 };
 struct Hit {
     std::shared_ptr<Material> mtl; glm::vec3 point, norm, color; float t; bool isHit;
-    Hit(bool h) : t(0.0f), isHit(h) {}
+    Hit(bool hit, const std::shared_ptr<Material> &m = std::shared_ptr<Material>(), const glm::vec3 &p = glm::vec3(),
+        const glm::vec3 &n = glm::vec3(), const glm::vec3 &c = glm::vec3(), float tt = 0.0f)
+        : mtl(m), point(p), norm(n), color(c), t(tt), isHit(hit) {}
 };
-struct Triangle { glm::vec3 p, e1, e2; glm::vec2 uvStart, uvU, uvV; glm::vec3 norm; std::shared_ptr<Material> material; };
-struct Sphere { glm::vec3 center; float radius; std::shared_ptr<Material> material; };
-struct Lamp { glm::vec3 pos; float intensity, distance; };
+struct Triangle {
+    glm::vec3 p, e1, e2; glm::vec2 uvStart, uvU, uvV; glm::vec3 norm; std::shared_ptr<Material> material;
+    Triangle(const glm::vec3 &p_, const glm::vec3 &a, const glm::vec3 &b, const glm::vec2 &u0, const glm::vec2 &uu, const glm::vec2 &uv,
+             const glm::vec3 &n, const std::shared_ptr<Material> &m) : p(p_), e1(a), e2(b), uvStart(u0), uvU(uu), uvV(uv), norm(n), material(m) {}
+};
+struct Sphere {
+    glm::vec3 center; float radius; std::shared_ptr<Material> material;
+    Sphere(const glm::vec3 &c, float r, const std::shared_ptr<Material> &m) : center(c), radius(r), material(m) {}
+};
+struct Lamp {
+    glm::vec3 pos; float intensity, distance;
+    Lamp(const glm::vec3 &p, float i, float d) : pos(p), intensity(i), distance(d) {}
+};
 struct Scene {
     std::vector<std::shared_ptr<Material>> materials;
     std::vector<std::shared_ptr<Triangle>> triangles;

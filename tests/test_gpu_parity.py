@@ -328,3 +328,40 @@ def test_bilinear_mode_matches_its_cpu_definition(backends, name):
         assert not np.array_equal(ref["linear"], near["linear"])          # the mode does something
         back = ex.render(W, H, mode=mode, max_depth=depth, tone=False)     # and is off again afterwards
         assert ulp_diff(back["rgb"], near["linear"]).max() <= 4
+
+
+@pytest.mark.parametrize("mode,depth", [(CL, 0), (CPU, 2)])
+def test_sub_rectangles_equal_the_frame_and_the_oracle(backends, mode, depth):
+    """hipexec_render_rect (the role of renderSubBlockCl, ray_tracer_cl.cpp:59-105): rectangles with unaligned
+    origins and sizes, partly or wholly outside the frame; inside the rectangle the oracle's pixels and ids, outside
+    it nothing is written; the 48x48 block walk of ray_tracer_cl.cpp:15-55 reassembles hipexec_render's frame."""
+    fs, ex, orc = backends("c2")
+    W, H = 107, 61
+    spp = 1 if mode == CL else 4
+    ref = orc.render(W, H, mode=mode, max_depth=depth, tone=1, n_threads=8)
+    full = ex.render(W, H, mode=mode, max_depth=depth, tone=True)
+    for (x, y, w, h) in [(0, 0, 48, 48), (48, 0, 48, 48), (96, 48, 11, 13), (5, 7, 1, 1), (13, 3, 70, 9), (100, 50, 48, 48),
+                         (-5, -3, 20, 10), (0, 60, 107, 1), (200, 10, 5, 5), (3, 3, 0, 4)]:
+        img = np.full((H, W, 3), -7.0, np.float32)
+        ids = np.full((H, W, spp), -9, np.int32)
+        st = ex.render_rect(W, H, x, y, w, h, img, mode=mode, max_depth=depth, ids=ids)
+        x0, y0, x1, y1 = max(0, x), max(0, y), max(0, min(W, x + w)), max(0, min(H, y + h))
+        inside = np.zeros((H, W), bool)
+        if x1 > x0 and y1 > y0:
+            inside[y0:y1, x0:x1] = True
+        assert (img[~inside] == -7.0).all() and (ids[~inside] == -9).all()
+        assert np.array_equal(img[inside].view(np.int32), full["rgb"][inside].view(np.int32))
+        assert np.array_equal(ids[inside], ref["ids"][inside])
+        assert st.rays_primary == int(inside.sum()) * spp
+        if inside.any():
+            assert_image_parity(img[inside], ref["rgb"][inside], min_frac=1.0)
+    walk = np.zeros((H, W, 3), np.float32)
+    rays = 0
+    for by in range(0, H, 48):
+        for bx in range(0, W, 48):
+            rays += ex.render_rect(W, H, bx, by, min(48, W - bx), min(48, H - by), walk, mode=mode, max_depth=depth).rays
+    assert np.array_equal(walk.view(np.int32), full["rgb"].view(np.int32))
+    assert rays == full["stats"].rays == ref["stats"].rays
+    with pytest.raises(RuntimeError):
+        ex._check(ex._lib.hipexec_render_rect(ex._h, C.byref(ex._cfg(W, H, mode, depth, True, 1, 2, False)), 0, 0, 8, 8,
+                                              walk.ctypes.data, None, None))
