@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -124,6 +125,18 @@ constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk o
 constexpr uint64_t BATCH_MAX_SAMPLES = 64ull << 20;          // samples per batch of a frame without a shadow queue
 constexpr uint32_t TAIL_MAX_RAYS = 300000u;                    // see use_tail
 constexpr int N_CNT64 = 17;                                  // device counters, see call_end
+constexpr int LV_SLOTS = 8;                                  // batches of one call (per lane) whose level counts are kept apart
+constexpr int LV_PER = 68;                                   // level counters per batch: entry L = rays queued for recursion level L (max_depth <= 64)
+
+// Ray-queue sizes of the recursion levels of one batch, remembered per executor lane.  Rendering is deterministic, so a
+// batch with the same key has the same queue sizes every time: the second and later frames size every launch from
+// the remembered counts and never wait for a count to come back from the device; the counts the kernels produced are
+// compared with the remembered ones when the call is collected, and a difference repeats the frame the waiting way.
+struct LevelPred {
+    std::array<int64_t, 24> key{};
+    std::vector<uint32_t> n;                                  // n[L], L >= 1, for the levels that were traced
+};
+struct LevelCheck { int slot; std::array<int64_t, 24> key; };
 
 // Fixed work memory of hipexec_any_hits_static (one copy per GPU, held until the process ends):
 // [0, 256) work counters, then the ray records (32 bytes per ray), then one occlusion word per ray.
@@ -167,6 +180,16 @@ struct hipexec {
     int closest_r = 3, anyhit_r = 2;          // rays per lane (tunable through HIPEXEC_CLOSEST_R / HIPEXEC_ANYHIT_R)
     unsigned long long *d_cnt64 = nullptr;    // [0] any-hit triangle tests, [1] any-hit sphere tests
     uint32_t *h_cnt32 = nullptr;              // pinned
+    uint32_t *d_lvl = nullptr, *h_lvl = nullptr;   // [LV_SLOTS][LV_PER] level queue fills of the call in progress (device / pinned)
+    int lv_slot = 0;                          // next free slot of the call in progress
+    std::vector<LevelPred> preds;             // remembered queue sizes (newest last, at most 64)
+    std::vector<LevelCheck> checks;           // batches of the call in progress that ran from remembered sizes
+    bool predict = true;                      // HIPEXEC_PREDICT=0: always wait for the counts
+    int predict_spoil = 0;                    // test hook: remembered level-1 sizes are stored this much too large (or too small)
+    bool predict_now = true;                  // false while a frame is being repeated after a failed check
+    bool redo = false;                        // a check failed: the frame has to be repeated
+    hipexec_render_cfg pending_cfg{};         // arguments of an asynchronous call, for such a repeat
+    float4 *pending_rgba = nullptr; int32_t *pending_ids = nullptr;
     unsigned long long *h_cnt64 = nullptr;    // pinned
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -527,9 +550,15 @@ int call_begin(hipexec *h, uint32_t timing, uint32_t flags)
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->side) HIPCHK(hipStreamSynchronize(h->side));
     }
+    // event pairs of a call that was never collected (a failed call, an asynchronous call followed by another call) go
+    // back to the pool; they must not be counted as launches of this call
+    for (TimedLaunch &t : h->timed) { h->event_pool.push_back(t.a); h->event_pool.push_back(t.b); }
+    h->timed.clear();
     h->timing = timing;
     memset(&h->acc, 0, sizeof h->acc);
     h->call_open = true;
+    h->lv_slot = 0; h->checks.clear();
+    HIPCHK(hipMemsetAsync(h->d_lvl, 0, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     return HIPEXEC_OK;
@@ -578,22 +607,88 @@ int call_end(hipexec *h, hipexec_stats *stats)
     }
     h->timed.clear();
     h->call_open = false;
+    // batches that ran from remembered queue sizes: the sizes the kernels produced must be the remembered ones
+    for (const LevelCheck &c : h->checks) {
+        const uint32_t *got = h->h_lvl + (size_t)c.slot * LV_PER;
+        for (size_t i = 0; i < h->preds.size(); i++) {
+            if (!(h->preds[i].key == c.key)) continue;
+            bool same = true;
+            for (size_t L = 1; L < h->preds[i].n.size(); L++) same = same && got[L] == h->preds[i].n[L];
+            if (!same) { h->preds.erase(h->preds.begin() + (long)i); h->redo = true; }
+            break;
+        }
+    }
+    h->checks.clear();
     // the other lanes' shares of the frame: their counters and kernel times are added to this call's
     for (hipexec *g : h->helpers) {
         if (!g->call_open) continue;
         CHK(call_end(g, nullptr));
         add_stats(h->acc, g->acc);
+        if (g->redo) { h->redo = true; g->redo = false; }
     }
     h->lanes_used = 1;
     if (stats) *stats = h->acc;
     return HIPEXEC_OK;
 }
 
-int read_count(hipexec *h, int which, uint32_t *out)
+// Queue sizes of the recursion levels of the batch being traced (see LevelPred).
+struct LevelRun {
+    int slot = -1;                       // counters of this batch: d_lvl[slot][level]; -1: the call has more batches than slots
+    const LevelPred *pred = nullptr;     // remembered sizes to run from, or null: every size is read back (and remembered)
+    LevelPred rec;
+};
+
+int level_begin(hipexec *h, const std::array<int64_t, 24> &key, bool may_predict, LevelRun &run)
 {
-    HIPCHK(hipMemcpyAsync(h->h_cnt32 + which, h->d_cnt32 + which, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    run.slot = h->lv_slot < LV_SLOTS ? h->lv_slot++ : -1;
+    run.pred = nullptr;
+    run.rec.key = key; run.rec.n.assign(1, 0u);
+    if (run.slot >= 0 && may_predict && h->predict && h->predict_now)
+        for (const LevelPred &p : h->preds) if (p.key == key) run.pred = &p;
+    return HIPEXEC_OK;
+}
+
+// device counter that the producers of level `level`'s rays add to
+uint32_t *level_counter(hipexec *h, const LevelRun &run, int level)
+{
+    return run.slot >= 0 ? h->d_lvl + (size_t)run.slot * LV_PER + level : h->d_cnt32;
+}
+
+// what the consumers of level `level`'s queue get as its device-side fill: the counter when the launch size is a
+// remembered one, nothing when it was read back from that counter (or is level 0, whose size the host computes)
+const uint32_t *level_fill(hipexec *h, const LevelRun &run, int level)
+{
+    return (run.pred && level >= 1) ? level_counter(h, run, level) : nullptr;
+}
+
+// number of rays queued for `level`, once its producers are enqueued on `stream`
+int level_count(hipexec *h, LevelRun &run, int level, uint32_t *out)
+{
+    if (run.pred) { *out = (size_t)level < run.pred->n.size() ? run.pred->n[(size_t)level] : 0u; return HIPEXEC_OK; }
+    uint32_t *src = level_counter(h, run, level);
+    HIPCHK(hipMemcpyAsync(h->h_cnt32, src, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    *out = h->h_cnt32[which];
+    *out = h->h_cnt32[0];
+    run.rec.n.resize((size_t)level + 1, 0u);
+    run.rec.n[(size_t)level] = *out;
+    return HIPEXEC_OK;
+}
+
+int level_end(hipexec *h, LevelRun &run)
+{
+    if (run.pred) {
+        // the counts the kernels produced come back with the call and are compared then (call_end)
+        HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)run.slot * LV_PER, h->d_lvl + (size_t)run.slot * LV_PER, LV_PER * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, h->stream));
+        h->checks.push_back(LevelCheck{run.slot, run.rec.key});
+    } else if (run.slot >= 0 && h->predict) {
+        for (size_t i = 0; i < h->preds.size(); i++) if (h->preds[i].key == run.rec.key) { h->preds.erase(h->preds.begin() + (long)i); break; }
+        if (h->preds.size() >= 64) h->preds.erase(h->preds.begin());
+        h->preds.push_back(run.rec);
+        // test hook: a wrong remembered size, so that the check of call_end and the repeat of the frame can be exercised
+        if (h->predict_spoil && h->preds.back().n.size() > 1 && (int64_t)h->preds.back().n[1] + h->predict_spoil > 0)
+            h->preds.back().n[1] = (uint32_t)((int64_t)h->preds.back().n[1] + h->predict_spoil);
+    }
     return HIPEXEC_OK;
 }
 
@@ -643,7 +738,8 @@ static uint32_t small_launch_share(uint32_t n, uint32_t full)
 }
 
 template <int MODE>
-int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t n, float4 *hits, int klass_count)
+int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t n, float4 *hits, int klass_count,
+                       const uint32_t *n_dev = nullptr)
 {
     if (h->packet && klass_count == 0) {
         // camera rays: the 64 rays of a wave are one 8x8-pixel tile of one sub-sample and walk the hierarchy as a packet
@@ -657,9 +753,9 @@ int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t 
                                                   : small_launch_share(n, klass_count == 0 ? 256u : 768u);
         uint32_t blocks = (n + per_block - 1) / per_block;
         LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count,
-               h->refill_closest | (h->sched_w << 8) | (int)(per_block << 16));
+               h->refill_closest | (h->sched_w << 8) | (int)(per_block << 16), n_dev);
     } else {
-        LAUNCH(klass_time, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count);
+        LAUNCH(klass_time, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
     }
     return HIPEXEC_OK;
 }
@@ -675,9 +771,9 @@ int launch_closest_r(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
     return HIPEXEC_OK;
 }
 template <int MODE>
-int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits)
+int launch_closest(hipexec *h, const float4 *rays, uint32_t n, float4 *hits, const uint32_t *n_dev = nullptr)
 {
-    if (h->use_bvh) return launch_bvh_closest<MODE>(h, HIPEXEC_K_CLOSEST, rays, n, hits, 1);
+    if (h->use_bvh) return launch_bvh_closest<MODE>(h, HIPEXEC_K_CLOSEST, rays, n, hits, 1, n_dev);
     switch (h->closest_r) {
     case 1: return launch_closest_r<MODE, 1>(h, rays, n, hits);
     case 3: return launch_closest_r<MODE, 3>(h, rays, n, hits);
@@ -706,10 +802,10 @@ bool use_tail(const hipexec *h, uint32_t n_rays, int level, int depth)
 }
 
 template <int MODE>
-int launch_tail(hipexec *h, const float4 *rays, uint32_t n, int level, int depth, size_t stride)
+int launch_tail(hipexec *h, const float4 *rays, uint32_t n, int level, int depth, size_t stride, const uint32_t *n_dev)
 {
     LAUNCH(HIPEXEC_K_CLOSEST, (k_bvh_tail<MODE>), blocks_for(n), h->S, h->B, rays, n, level, depth, h->local.as<float4>(), stride,
-           h->d_cnt64);
+           h->d_cnt64, n_dev);
     return HIPEXEC_OK;
 }
 
@@ -719,17 +815,17 @@ int launch_tail(hipexec *h, const float4 *rays, uint32_t n, int level, int depth
 // compaction with their barriers); HIPEXEC_SHADOW_DIRECT=0 selects the list form.
 template <int MODE, bool FUSED>
 int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const float4 *hits, uint32_t n, float4 *local_level, bool spawn,
-                      float4 *next_rays, uint32_t *next_count)
+                      float4 *next_rays, uint32_t *next_count, const uint32_t *n_dev)
 {
     const uint32_t per_block = small_launch_share(n, h->shadow_per_block);
     const uint32_t blocks = (n + per_block - 1) / per_block;
     const float4 *nodes_sc = h->uniform_fetch ? h->B.nodes : nullptr;
     if (h->shadow_direct)
         LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
-                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count);
+                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     else
         LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
-                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count);
+                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     return HIPEXEC_OK;
 }
 
@@ -740,7 +836,7 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
 // Buffers alternate by level; a level's ray and hit buffers are reused two levels later, which the
 // main stream does only after the side stream has finished with them (ev_lit).
 template <int MODE>
-int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, int *levels_used)
+int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, int *levels_used, LevelRun &run)
 {
     const DScene &S = h->S;
     float4 *ray_buf[2] = {h->rayA.as<float4>(), h->rayB.as<float4>()};
@@ -752,26 +848,27 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
     bool tail = false;
     for (;; level++) {
         const bool spawn = level < depth;
+        const uint32_t *n_dev = level_fill(h, run, level);
         HIPCHK(hipEventRecord(h->ev_hits[level & 1], main_s));               // this level's hits are complete
         if (spawn) {
             if (level >= 1) HIPCHK(hipStreamWaitEvent(main_s, h->ev_lit[(level - 1) & 1], 0));
-            HIPCHK(hipMemsetAsync(h->d_cnt32, 0, sizeof(uint32_t), main_s));
+            if (run.slot < 0) HIPCHK(hipMemsetAsync(h->d_cnt32, 0, sizeof(uint32_t), main_s));
             LAUNCH_ON(main_s, HIPEXEC_K_SHADE, (k_bounce<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, ray_buf[(level + 1) & 1],
-                      h->d_cnt32);
+                      level_counter(h, run, level + 1), n_dev);
         }
         HIPCHK(hipStreamWaitEvent(side_s, h->ev_hits[level & 1], 0));
         float4 *local_level = h->local.as<float4>() + (size_t)level * stride;
         if (fused_shading(h, true)) {
-            CHK((launch_bvh_shadow<MODE, true>(h, side_s, cur_rays, cur_hits, n, local_level, spawn, nullptr, nullptr)));
+            CHK((launch_bvh_shadow<MODE, true>(h, side_s, cur_rays, cur_hits, n, local_level, spawn, nullptr, nullptr, n_dev)));
         } else {
-            if (S.n_lamp) CHK((launch_bvh_shadow<MODE, false>(h, side_s, cur_rays, cur_hits, n, nullptr, false, nullptr, nullptr)));
+            if (S.n_lamp) CHK((launch_bvh_shadow<MODE, false>(h, side_s, cur_rays, cur_hits, n, nullptr, false, nullptr, nullptr, n_dev)));
             LAUNCH_ON(side_s, HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
-                      h->lamp_words, local_level, spawn, (float4 *)nullptr, (uint32_t *)nullptr);
+                      h->lamp_words, local_level, spawn, (float4 *)nullptr, (uint32_t *)nullptr, n_dev);
         }
         HIPCHK(hipEventRecord(h->ev_lit[level & 1], side_s));
         if (!spawn) break;
         uint32_t nn = 0;
-        CHK(read_count(h, 0, &nn));
+        CHK(level_count(h, run, level + 1, &nn));
         if (nn == 0) break;
         h->acc.rays_bounce += nn;
         h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
@@ -779,11 +876,11 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
         cur_rays = ray_buf[(level + 1) & 1];
         cur_hits = hit_buf[(level + 1) & 1];
         if (use_tail(h, nn, level + 1, depth)) {
-            CHK(launch_tail<MODE>(h, cur_rays, nn, level + 1, depth, stride));
+            CHK(launch_tail<MODE>(h, cur_rays, nn, level + 1, depth, stride, level_fill(h, run, level + 1)));
             tail = true;
             break;
         }
-        CHK(launch_bvh_closest<MODE>(h, HIPEXEC_K_CLOSEST, cur_rays, nn, cur_hits, 1));
+        CHK(launch_bvh_closest<MODE>(h, HIPEXEC_K_CLOSEST, cur_rays, nn, cur_hits, 1, level_fill(h, run, level + 1)));
         n = nn;
     }
     HIPCHK(hipStreamWaitEvent(main_s, h->ev_lit[level & 1], 0));             // the side stream is in order: every level is lit
@@ -791,32 +888,47 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
     return HIPEXEC_OK;
 }
 
+template <int MODE>
+int trace_levels_run(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *levels_used, LevelRun &run);
+
 // Shadow rays, shading and bounces for n0 level-0 rays whose records are in rayA and whose
 // closest hits are in hit0.  Leaves per-level colours in h->local ([level][stride]).
 template <int MODE>
-int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *levels_used)
+int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *levels_used, const std::array<int64_t, 24> &key)
+{
+    LevelRun run;
+    CHK(level_begin(h, key, h->use_bvh, run));
+    int rc = trace_levels_run<MODE>(h, n0, stride, max_depth, levels_used, run);
+    if (rc == HIPEXEC_OK) rc = level_end(h, run);
+    return rc;
+}
+
+template <int MODE>
+int trace_levels_run(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *levels_used, LevelRun &run)
 {
     const DScene &S = h->S;
     // Measured on C2 / C3 shards: with up to ~2 M samples per lane the overlap wins (1/8 of C2: 1.54 -> 1.45 ms,
     // 1/8 of C3: 3.47 -> 3.36 ms); larger batches fill the chip from the two lanes alone and only pay for k_bounce.
     const bool overlap = h->overlap_levels == 2 || (h->overlap_levels == 1 && n0 <= OVERLAP_MAX_SAMPLES);
     if (MODE == HIPEXEC_MODE_CPU && max_depth > 0 && h->use_bvh && h->bvh_refill && h->side && overlap)
-        return trace_levels_overlapped<MODE>(h, n0, stride, max_depth, levels_used);
+        return trace_levels_overlapped<MODE>(h, n0, stride, max_depth, levels_used, run);
     float4 *cur_rays = h->rayA.as<float4>(), *next_rays = h->rayB.as<float4>();
     float4 *cur_hits = h->hit0.as<float4>();
     uint32_t n = n0;
     int depth = (MODE == HIPEXEC_MODE_CL) ? 0 : std::max(0, max_depth);
     int level = 0;
     for (;; level++) {
-        HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
+        if (!h->use_bvh || run.slot < 0) HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
         const bool spawn = level < depth;
         float4 *local_level = h->local.as<float4>() + (size_t)level * stride;
+        uint32_t *next_count = level_counter(h, run, level + 1);
+        const uint32_t *n_dev = level_fill(h, run, level);
         bool shaded = false;
         if (h->use_bvh && fused_shading(h, false)) {
-            CHK((launch_bvh_shadow<MODE, true>(h, h->stream, cur_rays, cur_hits, n, local_level, spawn, next_rays, h->d_cnt32)));
+            CHK((launch_bvh_shadow<MODE, true>(h, h->stream, cur_rays, cur_hits, n, local_level, spawn, next_rays, next_count, n_dev)));
             shaded = true;
         } else if (S.n_lamp && h->use_bvh) {
-            CHK((launch_bvh_shadow<MODE, false>(h, h->stream, cur_rays, cur_hits, n, nullptr, false, nullptr, nullptr)));
+            CHK((launch_bvh_shadow<MODE, false>(h, h->stream, cur_rays, cur_hits, n, nullptr, false, nullptr, nullptr, n_dev)));
         } else if (S.n_lamp) {
             LAUNCH(HIPEXEC_K_SHADE, (k_shadowgen<MODE>), blocks_for(n), S, cur_rays, cur_hits, n,
                    h->shadowq.as<float4>(), h->d_cnt32 + 1);
@@ -831,20 +943,20 @@ int trace_levels(hipexec *h, uint32_t n0, size_t stride, int max_depth, int *lev
         }
         if (!shaded)
             LAUNCH(HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
-                   h->lamp_words, local_level, spawn, next_rays, h->d_cnt32);
+                   h->lamp_words, local_level, spawn, next_rays, next_count, n_dev);
         if (!spawn) break;
         uint32_t nn = 0;
-        CHK(read_count(h, 0, &nn));
+        CHK(level_count(h, run, level + 1, &nn));
         if (nn == 0) break;
         h->acc.rays_bounce += nn;
         h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
         h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
         if (use_tail(h, nn, level + 1, depth)) {
-            CHK(launch_tail<MODE>(h, next_rays, nn, level + 1, depth, stride));
+            CHK(launch_tail<MODE>(h, next_rays, nn, level + 1, depth, stride, level_fill(h, run, level + 1)));
             *levels_used = depth + 1;
             return HIPEXEC_OK;
         }
-        CHK(launch_closest<MODE>(h, next_rays, nn, h->hitN.as<float4>()));
+        CHK(launch_closest<MODE>(h, next_rays, nn, h->hitN.as<float4>(), level_fill(h, run, level + 1)));
         std::swap(cur_rays, next_rays);
         cur_hits = h->hitN.as<float4>();
         n = nn;
@@ -938,7 +1050,10 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         h->acc.tests_tri_closest += prim * S.n_tri;
         h->acc.tests_sph_closest += prim * S.n_sph;
         int levels_used = 1;
-        CHK(trace_levels<MODE>(h, (uint32_t)n0, (size_t)n0, depth, &levels_used));
+        const std::array<int64_t, 24> key = {1, c->width, c->height, MODE, depth, c->tile_first, c->tile_step, h->win_lo, h->win_hi,
+                                             cx0, cy0, cx1, cy1, sub, n_sub, t0, (int64_t)n0, h->use_bvh, h->tail_max, h->overlap_levels,
+                                             h->bvh_refill, h->fuse_shade, (int64_t)h->simple_from, 0};
+        CHK(trace_levels<MODE>(h, (uint32_t)n0, (size_t)n0, depth, &levels_used, key));
         LAUNCH(HIPEXEC_K_SHADE, (k_resolve<MODE>), blocks_for(F.n_slots), F, h->local.as<float4>(), (size_t)n0, levels_used,
                h->hit0.as<float4>(), c->tone, d_rgba, d_ids);
     }
@@ -972,6 +1087,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
         hipexec *g = h->helpers[(size_t)k - 1];
         g->win_lo = h->win_lo; g->win_hi = h->win_hi;
         for (int q = 0; q < 4; q++) g->rect[q] = h->rect[q];
+        g->predict_now = h->predict_now;
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
         g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
         g->worker->submit([&, g, k]() {
@@ -986,12 +1102,18 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     }
     int rc = render_sub(h, c, d_rgba, d_ids, 0, L);
     for (int k = 1; k < L; k++) h->helpers[(size_t)k - 1]->worker->wait();
-    // join: later work on this executor's stream waits for the other lanes' kernels
+    // join: later work on this executor's stream waits for the other lanes' kernels.  Every lane is joined whatever
+    // happens to one of them; the first error is the call's.
     for (int k = 1; k < L; k++) {
         hipexec *g = h->helpers[(size_t)k - 1];
         if (rcs[(size_t)k] == HIPEXEC_OK) {
-            HIPCHK(hipEventRecord(g->ev_join, g->stream));
-            HIPCHK(hipStreamWaitEvent(h->stream, g->ev_join, 0));
+            hipError_t e = hipEventRecord(g->ev_join, g->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, g->ev_join, 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(g->stream);
+                g->call_open = false;
+                if (rc == HIPEXEC_OK) rc = fail(HIPEXEC_E_DEVICE, "joining lane %d failed: %s", k, hipGetErrorString(e));
+            }
         } else {
             (void)hipStreamSynchronize(g->stream);
             g->call_open = false;
@@ -1057,12 +1179,30 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     h->n_cnt32 = std::max(8u, n_lamp + 1u);
     HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&h->d_cnt64, N_CNT64 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&h->d_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void **)&h->h_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), hipHostMallocDefault));
+    if (const char *e = getenv("HIPEXEC_PREDICT")) h->predict = atoi(e) != 0;
+    if (const char *e = getenv("HIPEXEC_PREDICT_SPOIL")) h->predict_spoil = atoi(e);   // test hook, see level_end
     HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_cnt64, N_CNT64 * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return HIPEXEC_OK;
+}
+
+// Runs `frame` (call_begin ... call_end); if one of its batches ran from remembered queue sizes and the kernels
+// produced other sizes (the check of call_end), the frame is traced once more with every size read back.
+template <class F>
+int run_checked(hipexec *h, F frame)
+{
+    int rc = frame();
+    if (rc == HIPEXEC_OK && h->redo) {
+        h->redo = false; h->predict_now = false;
+        rc = frame();
+        h->predict_now = true; h->redo = false;
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1144,6 +1284,8 @@ void hipexec_destroy(hipexec_t *h)
                    &h->stage_in, &h->stage_out}) b->release();
     if (h->d_cnt32) (void)hipFree(h->d_cnt32);
     if (h->d_cnt64) (void)hipFree(h->d_cnt64);
+    if (h->d_lvl) (void)hipFree(h->d_lvl);
+    if (h->h_lvl) (void)hipHostFree(h->h_lvl);
     if (h->h_cnt32) (void)hipHostFree(h->h_cnt32);
     if (h->h_cnt64) (void)hipHostFree(h->h_cnt64);
     for (TimedLaunch &t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -1178,7 +1320,16 @@ int hipexec_sync(hipexec_t *h)
     if (h->call_open) {
         hipexec_stats *dst = h->pending_stats;
         h->pending_stats = nullptr;
-        return call_end(h, dst);
+        bool first = true;
+        return run_checked(h, [&]() -> int {
+            if (!first) {          // repeat of the asynchronous frame (hipexec_render_device) with its saved arguments
+                CHK(call_begin(h, timing_mask(h->pending_cfg.flags), h->pending_cfg.flags));
+                int rc = render_dispatch(h, &h->pending_cfg, h->pending_rgba, h->pending_ids);
+                if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
+            }
+            first = false;
+            return call_end(h, dst);
+        });
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return HIPEXEC_OK;
@@ -1195,6 +1346,7 @@ int hipexec_render_device(hipexec_t *h, const hipexec_render_cfg *cfg, float *d_
     if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
     h->pending_stats = stats;
+    h->pending_cfg = *cfg; h->pending_rgba = reinterpret_cast<float4 *>(d_out_rgba); h->pending_ids = d_out_ids;
     return HIPEXEC_OK;
 }
 
@@ -1210,21 +1362,24 @@ int hipexec_render(hipexec_t *h, const hipexec_render_cfg *cfg, float *out_rgb, 
     HIPCHK(hipSetDevice(h->device));
     CHK(h->out_rgba.reserve(rows * W * 16));
     if (out_ids) CHK(h->out_ids.reserve(rows * W * 4 * spp));
-    CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
-    int rc = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
-    if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
-    if (cfg->tile_first == 0 && cfg->tile_step == 1) {
-        // whole frame: rows are already in frame order; drop the alpha lane on the device and copy
-        // straight into the caller's image (24 instead of 32 bytes per pixel over PCIe, no host pass)
-        const size_t n_px = (size_t)cfg->height * W;
-        CHK(h->stage_out.reserve(n_px * 12));
-        LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>(), n_px, h->stage_out.as<float>());
-        CHK(call_end(h, stats));
+    const bool whole = cfg->tile_first == 0 && cfg->tile_step == 1;
+    const size_t n_px = (size_t)cfg->height * W;
+    if (whole) CHK(h->stage_out.reserve(n_px * 12));
+    CHK(run_checked(h, [&]() -> int {
+        CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
+        int rc = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
+        if (rc != HIPEXEC_OK) { h->call_open = false; return rc; }
+        // whole frame: rows are already in frame order; drop the alpha lane on the device
+        // (24 instead of 32 bytes per pixel over PCIe, no host pass)
+        if (whole) LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>(), n_px, h->stage_out.as<float>());
+        return call_end(h, stats);
+    }));
+    if (whole) {
+        // copy straight into the caller's image
         HIPCHK(hipMemcpy(out_rgb, h->stage_out.p, n_px * 12, hipMemcpyDeviceToHost));
         if (out_ids) HIPCHK(hipMemcpy(out_ids, h->out_ids.p, n_px * spp * sizeof(int32_t), hipMemcpyDeviceToHost));
         return HIPEXEC_OK;
     }
-    CHK(call_end(h, stats));
     std::vector<float> rgba(rows * W * 4);
     HIPCHK(hipMemcpy(rgba.data(), h->out_rgba.p, rgba.size() * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> ids;
@@ -1264,14 +1419,16 @@ int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int3
     for (int t0 = 0; t0 < n_tiles && rc == HIPEXEC_OK; t0 += tiles_per_step) {
         rc = [&]() -> int {
             h->win_lo = t0; h->win_hi = std::min(n_tiles, t0 + tiles_per_step);
-            CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
-            int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), nullptr);
-            if (r != HIPEXEC_OK) { h->call_open = false; return r; }
             const int y0 = t0 * HIPEXEC_TILE_ROWS, rows = std::min(cfg->height, h->win_hi * HIPEXEC_TILE_ROWS) - y0;
             const size_t n_px = (size_t)rows * W;
-            LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>() + (size_t)y0 * W, n_px, h->stage_out.as<float>());
             hipexec_stats st{};
-            CHK(call_end(h, &st));
+            CHK(run_checked(h, [&]() -> int {
+                CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
+                int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), nullptr);
+                if (r != HIPEXEC_OK) { h->call_open = false; return r; }
+                LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>() + (size_t)y0 * W, n_px, h->stage_out.as<float>());
+                return call_end(h, &st);
+            }));
             HIPCHK(hipMemcpy(out_rgb + (size_t)y0 * W * 3, h->stage_out.p, n_px * 12, hipMemcpyDeviceToHost));
             add_stats(total, st);
             total.total_ms += st.total_ms; total.algorithm = st.algorithm; total.lanes = std::max(total.lanes, st.lanes);
@@ -1307,12 +1464,14 @@ int hipexec_render_rect(hipexec_t *h, const hipexec_render_cfg *cfg, int32_t x, 
     h->win_lo = t_lo; h->win_hi = t_hi;
     h->rect[0] = x0; h->rect[1] = y0; h->rect[2] = x1; h->rect[3] = y1;
     int rc = [&]() -> int {
-        CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
-        int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
-        if (r != HIPEXEC_OK) { h->call_open = false; return r; }
         const size_t n_px = (size_t)(y1 - y0) * rw;
-        LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>() + (size_t)y0 * rw, n_px, h->stage_out.as<float>());
-        CHK(call_end(h, stats));
+        CHK(run_checked(h, [&]() -> int {
+            CHK(call_begin(h, timing_mask(cfg->flags), cfg->flags));
+            int r = render_dispatch(h, cfg, h->out_rgba.as<float4>(), out_ids ? h->out_ids.as<int32_t>() : nullptr);
+            if (r != HIPEXEC_OK) { h->call_open = false; return r; }
+            LAUNCH(HIPEXEC_K_SHADE, k_strip_alpha, blocks_for(n_px), h->out_rgba.as<float4>() + (size_t)y0 * rw, n_px, h->stage_out.as<float>());
+            return call_end(h, stats);
+        }));
         HIPCHK(hipMemcpy2D(out_rgb + ((size_t)y0 * cfg->width + x0) * 3, (size_t)cfg->width * 12, h->stage_out.p, rw * 12, rw * 12,
                            (size_t)(y1 - y0), hipMemcpyDeviceToHost));
         if (out_ids)
@@ -1419,6 +1578,9 @@ int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6
     if (n == 0) { if (stats) memset(stats, 0, sizeof *stats); return HIPEXEC_OK; }
     if (!rays6 || !colours3) return fail(HIPEXEC_E_INVALID, "rays6/colours3 is NULL");
     CHK(call_begin(h, false, 0));
+    h->predict_now = false;                       // the rays of a batch call are the caller's: no remembered queue sizes apply
+    const std::array<int64_t, 24> no_key{};
+    int rc = [&]() -> int {
     const DScene &S = h->S;
     int depth = mode == HIPEXEC_MODE_CL ? 0 : max_depth;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(BATCH_API_CHUNK, SHADOW_QUEUE_MAX_ENTRIES / std::max(1u, S.n_lamp)));
@@ -1434,10 +1596,10 @@ int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6
         int levels_used = 1;
         if (mode == HIPEXEC_MODE_CL) {
             CHK(launch_closest<HIPEXEC_MODE_CL>(h, h->rayA.as<float4>(), m, h->hit0.as<float4>()));
-            CHK(trace_levels<HIPEXEC_MODE_CL>(h, m, m, depth, &levels_used));
+            CHK(trace_levels<HIPEXEC_MODE_CL>(h, m, m, depth, &levels_used, no_key));
         } else {
             CHK(launch_closest<HIPEXEC_MODE_CPU>(h, h->rayA.as<float4>(), m, h->hit0.as<float4>()));
-            CHK(trace_levels<HIPEXEC_MODE_CPU>(h, m, m, depth, &levels_used));
+            CHK(trace_levels<HIPEXEC_MODE_CPU>(h, m, m, depth, &levels_used, no_key));
         }
         LAUNCH(HIPEXEC_K_SHADE, k_resolve_batch, blocks_for(m), m, h->local.as<float4>(), (size_t)m, levels_used,
                h->stage_out.as<float>());
@@ -1445,6 +1607,9 @@ int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return call_end(h, stats);
+    }();
+    h->predict_now = true;
+    return rc;
 }
 
 }  // extern "C"

@@ -658,10 +658,11 @@ constexpr int REFILL_BELOW = 44;       // active lanes below which a wave goes b
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest_p(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                        float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
-                                                       int klass, int refill_below)
+                                                       int klass, int refill_below, const uint32_t *__restrict__ n_dev)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ uint32_t next;
+    n = queue_fill(n, n_dev);
     const uint32_t per_block = (uint32_t)refill_below >> 16;          // rays owned by a block
     const uint32_t base = xcd_block() * per_block;
     const uint32_t end = min(n, base + per_block);
@@ -753,9 +754,10 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                      float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
-                                                     int klass)
+                                                     int klass, const uint32_t *__restrict__ n_dev)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
+    n = queue_fill(n, n_dev);
     uint32_t j = xcd_block() * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
@@ -866,8 +868,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                                                     uint32_t *__restrict__ occl, uint32_t lw,
                                                     unsigned long long *__restrict__ counters, uint32_t per_block,
                                                     const float4 *__restrict__ nodes_sc, float4 *__restrict__ local, int spawn,
-                                                    float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
+                                                    float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count,
+                                                    const uint32_t *__restrict__ n_dev)
 {
+    n = queue_fill(n, n_dev);
     __shared__ uint32_t occ_lds[FUSED ? 256 : 1];          // FUSED (at most 32 lamps): the block's occlusion bits stay here
     __shared__ uint32_t stack[BVH_STACK][256];
     __shared__ float Px[256], Py[256], Pz[256];
@@ -984,8 +988,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                                                     uint32_t *__restrict__ occl, uint32_t lw,
                                                     unsigned long long *__restrict__ counters, uint32_t per_block,
                                                     const float4 *__restrict__ nodes_sc, float4 *__restrict__ local, int spawn,
-                                                    float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
+                                                    float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count,
+                                                    const uint32_t *__restrict__ n_dev)
 {
+    n = queue_fill(n, n_dev);
     __shared__ uint32_t stack[BVH_STACK][256];
     // The spheres are tested one after the other for every shadow ray, each test behind a load of its own: from LDS
     // that load takes a tenth of the time it takes from the vector cache (first SPH_LDS spheres; the rest from memory).
@@ -1064,9 +1070,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_tail(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n, int level0,
                                                   int depth, float4 *__restrict__ local, size_t level_stride,
-                                                  unsigned long long *__restrict__ counters)
+                                                  unsigned long long *__restrict__ counters, const uint32_t *__restrict__ n_dev)
 {
     __shared__ uint32_t stack[BVH_STACK][256];
+    n = queue_fill(n, n_dev);
     uint32_t *stk = &stack[0][threadIdx.x];
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     bool alive = j < n;

@@ -41,6 +41,10 @@ DEV void load_ray(const float4 *rays, uint32_t j, f3 &o, f3 &d, uint32_t &s, uin
     o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y);
     s = __float_as_uint(b.z); aux = __float_as_uint(b.w);
 }
+// Fill of a ray queue: `n` is the size the host launched for (known exactly, or remembered from an identical earlier
+// batch); n_dev, when given, is the device counter the queue's producers added to.  A kernel never reads past either.
+DEV uint32_t queue_fill(uint32_t n, const uint32_t *__restrict__ n_dev) { return n_dev ? min(n, *n_dev) : n; }
+
 DEV void store_ray(float4 *rays, uint32_t j, f3 o, f3 d, uint32_t s, uint32_t aux) {
     rays[2 * (size_t)j] = make_float4(o.x, o.y, o.z, d.x);
     rays[2 * (size_t)j + 1] = make_float4(d.y, d.z, __uint_as_float(s), __uint_as_float(aux));
@@ -916,8 +920,10 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_shade(DScene S, const float4 *__restrict__ rays, const float4 *__restrict__ hits,
                                                uint32_t n, uint32_t *__restrict__ occl, uint32_t lw,
                                                float4 *__restrict__ local, bool spawn,
-                                               float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
+                                               float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count,
+                                               const uint32_t *__restrict__ n_dev)
 {
+    n = queue_fill(n, n_dev);
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
@@ -943,8 +949,10 @@ __global__ __launch_bounds__(256) void k_shade(DScene S, const float4 *__restric
 // ---------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bounce(DScene S, const float4 *__restrict__ rays, const float4 *__restrict__ hits,
-                                                uint32_t n, float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count)
+                                                uint32_t n, float4 *__restrict__ next_rays, uint32_t *__restrict__ next_count,
+                                                const uint32_t *__restrict__ n_dev)
 {
+    n = queue_fill(n, n_dev);
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;

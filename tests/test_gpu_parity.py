@@ -365,3 +365,50 @@ def test_sub_rectangles_equal_the_frame_and_the_oracle(backends, mode, depth):
     with pytest.raises(RuntimeError):
         ex._check(ex._lib.hipexec_render_rect(ex._h, C.byref(ex._cfg(W, H, mode, depth, True, 1, 2, False)), 0, 0, 8, 8,
                                               walk.ctypes.data, None, None))
+
+
+@pytest.mark.parametrize("spoil", ["0", "64", "-64", "off"])
+def test_remembered_queue_sizes(monkeypatch, spoil):
+    """From the second frame of a configuration on, the launches of the recursion levels are sized from the queue
+    sizes the first frame produced, without waiting for counts, and the produced counts are checked when the call is
+    collected.  HIPEXEC_PREDICT_SPOIL stores wrong sizes (too large / too small): the check must catch it and the frame
+    must come out right all the same; HIPEXEC_PREDICT=0 always waits.  Synchronous, sharded and asynchronous
+    (device-resident) frames against the oracle, three frames each."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    from tests.util import HipMem
+    if spoil == "off":
+        monkeypatch.setenv("HIPEXEC_PREDICT", "0")
+    else:
+        monkeypatch.setenv("HIPEXEC_PREDICT_SPOIL", spoil)
+    fs = scenegen.small_variant("mirror").to_flat()
+    W, H, depth = 48, 132, 4
+    ref = Oracle(fs).render(W, H, mode=CPU, max_depth=depth, tone=0, n_threads=8)
+    hip = HipMem()
+    d_out = hip.malloc(((H + 7) // 8) * 8 * W * 16)
+    try:
+        with HipExecutor(fs, device=0) as ex:
+            for _ in range(3):
+                got = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
+                assert np.array_equal(got["ids"], ref["ids"])
+                assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+                for k in ("rays_primary", "rays_bounce", "rays_shadow"):
+                    assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
+            first = got["rgb"].copy()
+            for _ in range(3):                                  # two interleaved shards, each with sizes of its own
+                img = np.zeros((H, W, 3), np.float32)
+                rays = sum(ex.render(W, H, mode=CPU, max_depth=depth, tone=False, tile_first=r, tile_step=2, out=img,
+                                     want_ids=False)["stats"].rays for r in range(2))
+                assert np.array_equal(img.view(np.int32), first.view(np.int32)) and rays == ref["stats"].rays
+            for _ in range(3):                                  # asynchronous, device-resident: collected by sync()
+                st = _abi.Stats()
+                hip.memset(d_out, 0, ((H + 7) // 8) * 8 * W * 16)
+                hip.sync()
+                ex.render_device(W, H, d_out, None, mode=CPU, max_depth=depth, tone=False, stats=st)
+                ex.sync()
+                out = np.zeros((((H + 7) // 8) * 8, W, 4), np.float32)
+                hip.d2h(out, d_out)
+                assert np.array_equal(out[:H, :, :3].view(np.int32), first.view(np.int32))
+                assert st.rays == ref["stats"].rays
+    finally:
+        hip.free(d_out)

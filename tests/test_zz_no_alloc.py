@@ -2,8 +2,6 @@
 hipexec_any_hits on the same rays: identical occlusion flags, on two calls in a row, the second with a
 smaller input (the fixed array keeps the first call's contents), for both algorithms and both rule sets,
 plus the size limit.  Device memory for the rays and flags is the test's own (plain hipMalloc)."""
-import ctypes as C
-
 import numpy as np
 import pytest
 
@@ -14,36 +12,7 @@ pytestmark = pytest.mark.gpu
 CPU, CL = _abi.HIPEXEC_MODE_CPU, _abi.HIPEXEC_MODE_CL
 
 
-class _Hip:
-    """The few HIP runtime calls the test needs for its own buffers."""
-
-    def __init__(self):
-        try:
-            self.lib = C.CDLL("libamdhip64.so")
-        except OSError:
-            self.lib = C.CDLL("/opt/rocm/lib/libamdhip64.so")
-        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        self.lib.hipFree.argtypes = [C.c_void_p]
-        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.lib.hipDeviceSynchronize.argtypes = []
-
-    def malloc(self, n):
-        p = C.c_void_p()
-        assert self.lib.hipMalloc(C.byref(p), n) == 0
-        return p.value
-
-    def free(self, p):
-        assert self.lib.hipFree(C.c_void_p(p)) == 0
-
-    def h2d(self, dst, arr):
-        arr = np.ascontiguousarray(arr)
-        assert self.lib.hipMemcpy(C.c_void_p(dst), C.c_void_p(arr.ctypes.data), arr.nbytes, 1) == 0
-
-    def d2h(self, arr, src):
-        assert self.lib.hipMemcpy(C.c_void_p(arr.ctypes.data), C.c_void_p(src), arr.nbytes, 2) == 0
-
-    def sync(self):
-        assert self.lib.hipDeviceSynchronize() == 0
+from tests.util import HipMem as _Hip
 
 
 def _rays(n, seed):

@@ -29,3 +29,41 @@ def assert_image_parity(got_rgb, ref_rgb, min_frac=0.999, min_psnr=50.0):
     assert frac >= min_frac, f"only {frac:.5f} of pixels within 1 LSB"
     assert p >= min_psnr, f"PSNR {p:.2f} dB"
     return frac, p
+
+
+class HipMem:
+    """The few HIP runtime calls a test needs for device buffers of its own (plain hipMalloc / hipMemcpy)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        try:
+            self.lib = C.CDLL("libamdhip64.so")
+        except OSError:
+            self.lib = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.lib.hipDeviceSynchronize.argtypes = []
+
+    def malloc(self, n):
+        p = self.C.c_void_p()
+        assert self.lib.hipMalloc(self.C.byref(p), n) == 0
+        return p.value
+
+    def free(self, p):
+        assert self.lib.hipFree(self.C.c_void_p(p)) == 0
+
+    def h2d(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        assert self.lib.hipMemcpy(self.C.c_void_p(dst), self.C.c_void_p(arr.ctypes.data), arr.nbytes, 1) == 0
+
+    def d2h(self, arr, src):
+        assert self.lib.hipMemcpy(self.C.c_void_p(arr.ctypes.data), self.C.c_void_p(src), arr.nbytes, 2) == 0
+
+    def memset(self, p, v, n):
+        assert self.lib.hipMemset(self.C.c_void_p(p), v, n) == 0
+
+    def sync(self):
+        assert self.lib.hipDeviceSynchronize() == 0

@@ -3,8 +3,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-starts = [i for i, n in enumerate(names) if 'k_raygen' in n]
-# the last frame begins at the first k_raygen of the last group of two (one per lane)
+starts = [i for i, n in enumerate(names) if 'k_raygen' in n or 'k_bvh_closest_pk' in n or 'k_primary' in n]
+# the last frame begins at the first camera-ray kernel of the last group of two (one per lane)
 first = starts[-2] if len(starts) >= 2 and int(rows[starts[-1]]['Start_Timestamp']) - int(rows[starts[-2]]['Start_Timestamp']) < 2_000_000 else starts[-1]
 t0 = int(rows[first]['Start_Timestamp'])
 busy = []
