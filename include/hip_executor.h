@@ -206,6 +206,17 @@ void hipexec_destroy(hipexec_t *h);
 int hipexec_set_stream(hipexec_t *h, void *stream);
 
 /*
+ * Concurrent lanes a frame with reflection levels is spread over (1..8, default 2; no counterpart in the reference).
+ * Lane k of L traces every L-th tile of the call on streams of its own, so that the thinly populated deep levels of
+ * one lane run beside the large launches of another.  A single frame at a time is fastest with 2.  For throughput
+ * over many frames keep TWO executors of the same scene with ONE lane each and give them the frames in turn
+ * (hipexec_render_device is asynchronous; collect a frame with hipexec_sync just before its executor gets the next
+ * one): the frames then overlap the same way, by a whole phase, and a process's four hardware queues are not
+ * oversubscribed.  Call it before the first frame: lanes that were never used cost nothing.
+ */
+int hipexec_set_lanes(hipexec_t *h, int lanes);
+
+/*
  * Algorithm (HIPEXEC_ALGO_*) of later calls that do not choose one through
  * hipexec_render_cfg.flags, including the batch entry points.  The reference has one
  * algorithm, the linear scans of ray_tracer.cpp:205-229 / opencl_executor.cpp:110-316

@@ -124,7 +124,9 @@ constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte
 constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk of the batch entry points
 constexpr uint64_t BATCH_MAX_SAMPLES = 64ull << 20;          // samples per batch of a frame without a shadow queue
 constexpr uint32_t TAIL_MAX_RAYS = 300000u;                    // see use_tail
-constexpr int N_CNT64 = 17;                                  // device counters, see call_end
+constexpr int N_CNT64 = 17;                                  // device counters in use per stripe, see call_end
+constexpr size_t CNT64_WORDS = (size_t)CNT_STRIPES * CNT_STRIDE;   // all stripes
+static_assert(N_CNT64 <= (int)CNT_STRIDE, "counters fit a stripe");
 constexpr int LV_SLOTS = 8;                                  // batches of one call (per lane) whose level counts are kept apart
 constexpr int LV_PER = 68;                                   // level counters per batch: entry L = rays queued for recursion level L (max_depth <= 64)
 
@@ -140,11 +142,10 @@ struct LevelCheck { int slot; std::array<int64_t, 24> key; };
 
 // Fixed work memory of hipexec_any_hits_static (one copy per GPU, held until the process ends):
 // [0, 256) work counters, then the ray records (32 bytes per ray), then one occlusion word per ray.
-constexpr size_t STATIC_CNT_BYTES = 256;
+constexpr size_t STATIC_CNT_BYTES = CNT64_WORDS * sizeof(unsigned long long);
 constexpr size_t STATIC_REC_BYTES = (size_t)HIPEXEC_STATIC_MAX_RAYS * 32;
 constexpr size_t STATIC_OCC_BYTES = (size_t)HIPEXEC_STATIC_MAX_RAYS * 4;
 constexpr size_t STATIC_BYTES = STATIC_CNT_BYTES + STATIC_REC_BYTES + STATIC_OCC_BYTES;
-static_assert(N_CNT64 * sizeof(unsigned long long) <= STATIC_CNT_BYTES, "counters fit their slot");
 constexpr int STATIC_MAX_DEVICES = 64;
 
 }  // namespace
@@ -222,6 +223,8 @@ struct hipexec {
     bool shadow_direct = true;                // HIPEXEC_SHADOW_DIRECT=0: shadow rays through the block's list in LDS (k_bvh_shadow)
     uint32_t shadow_per_block = 256u;         // HIPEXEC_SHADOW_PER_BLOCK: samples owned by a block of k_bvh_shadow (multiple of 64, <= 256)
     uint32_t tail_max = TAIL_MAX_RAYS;        // HIPEXEC_TAIL_MAX: largest ray queue handed to k_bvh_tail (0: never)
+    int block_closest = 256, block_shadow = 256, block_tail = 256;   // HIPEXEC_BLOCK_CLOSEST / _SHADOW / _TAIL: threads per block of the traversal kernels
+    uint32_t block64_below = 2500000u;        // HIPEXEC_BLOCK64_BELOW: launches of at most this many rays take one wave per block
     int overlap_levels = 1;                   // HIPEXEC_OVERLAP: 0 never, 1 for batches up to OVERLAP_MAX_SAMPLES, 2 always
 };
 
@@ -522,12 +525,13 @@ int timed_end(hipexec *h, hipStream_t stream)
     HIPCHK(hipEventRecord(h->timed.back().b, stream));
     return HIPEXEC_OK;
 }
-#define LAUNCH_ON(stream_, klass, kernel, grid, ...)                                           \
+#define LAUNCH_BS(stream_, klass, kernel, grid, bs, ...)                                       \
     do {                                                                                       \
         CHK(timed_begin(h, klass, stream_));                                                   \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream_, __VA_ARGS__);            \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(bs), 0, stream_, __VA_ARGS__);             \
         CHK(timed_end(h, stream_));                                                            \
     } while (0)
+#define LAUNCH_ON(stream_, klass, kernel, grid, ...) LAUNCH_BS(stream_, klass, kernel, grid, 256, __VA_ARGS__)
 #define LAUNCH(klass, kernel, grid, ...) LAUNCH_ON(h->stream, klass, kernel, grid, __VA_ARGS__)
 
 // kernel classes to time: none without HIPEXEC_FLAG_TIME_KERNELS, else those named by HIPEXEC_FLAG_TIME_CLASS (all if none is named)
@@ -559,7 +563,7 @@ int call_begin(hipexec *h, uint32_t timing, uint32_t flags)
     h->call_open = true;
     h->lv_slot = 0; h->checks.clear();
     HIPCHK(hipMemsetAsync(h->d_lvl, 0, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, CNT64_WORDS * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     return HIPEXEC_OK;
 }
@@ -582,8 +586,10 @@ void add_stats(hipexec_stats &d, const hipexec_stats &a)
 int call_end(hipexec *h, hipexec_stats *stats)
 {
     HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, N_CNT64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_cnt64, h->d_cnt64, CNT64_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (uint32_t st = 1; st < CNT_STRIPES; st++)           // the stripes add up in stripe 0
+        for (int k = 0; k < N_CNT64; k++) h->h_cnt64[k] += h->h_cnt64[(size_t)st * CNT_STRIDE + k];
     h->acc.tests_tri_any = h->h_cnt64[0];
     h->acc.tests_sph_any = h->h_cnt64[1];
     for (int k = 0; k < 3; k++) {
@@ -755,7 +761,12 @@ int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t 
         LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count,
                h->refill_closest | (h->sched_w << 8) | (int)(per_block << 16), n_dev);
     } else {
-        LAUNCH(klass_time, (k_bvh_closest<MODE>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
+        if (h->block_closest == 64 || n <= h->block64_below)
+            LAUNCH_BS(h->stream, klass_time, (k_bvh_closest<MODE, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
+        else if (h->block_closest == 128)
+            LAUNCH_BS(h->stream, klass_time, (k_bvh_closest<MODE, 128>), (n + 127u) / 128u, 128, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
+        else
+            LAUNCH(klass_time, (k_bvh_closest<MODE, 256>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
     }
     return HIPEXEC_OK;
 }
@@ -804,8 +815,12 @@ bool use_tail(const hipexec *h, uint32_t n_rays, int level, int depth)
 template <int MODE>
 int launch_tail(hipexec *h, const float4 *rays, uint32_t n, int level, int depth, size_t stride, const uint32_t *n_dev)
 {
-    LAUNCH(HIPEXEC_K_CLOSEST, (k_bvh_tail<MODE>), blocks_for(n), h->S, h->B, rays, n, level, depth, h->local.as<float4>(), stride,
-           h->d_cnt64, n_dev);
+    if (h->block_tail == 64 || n <= h->block64_below)
+        LAUNCH_BS(h->stream, HIPEXEC_K_CLOSEST, (k_bvh_tail<MODE, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, n, level, depth,
+                  h->local.as<float4>(), stride, h->d_cnt64, n_dev);
+    else
+        LAUNCH(HIPEXEC_K_CLOSEST, (k_bvh_tail<MODE, 256>), blocks_for(n), h->S, h->B, rays, n, level, depth, h->local.as<float4>(), stride,
+               h->d_cnt64, n_dev);
     return HIPEXEC_OK;
 }
 
@@ -820,8 +835,11 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
     const uint32_t per_block = small_launch_share(n, h->shadow_per_block);
     const uint32_t blocks = (n + per_block - 1) / per_block;
     const float4 *nodes_sc = h->uniform_fetch ? h->B.nodes : nullptr;
-    if (h->shadow_direct)
-        LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
+    if (h->shadow_direct && (h->block_shadow == 64 || n <= h->block64_below))
+        LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
+                  h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
+    else if (h->shadow_direct)
+        LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
                   h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     else
         LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
@@ -1067,6 +1085,25 @@ int render_sub(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t 
 }
 
 int call_begin(hipexec *h, uint32_t timing, uint32_t flags);
+int create_lane_resources(hipexec *h, uint32_t n_lamp);
+
+// Makes the lanes 1 .. want-1 of this executor if they do not exist yet (own streams, buffers, counters and host
+// thread each; the scene stays owned by lane 0).
+int more_lanes(hipexec *h, int want)
+{
+    while (h->bvh_ok && (int)h->helpers.size() + 1 < want) {
+        hipexec *g = new (std::nothrow) hipexec();
+        if (!g) return fail(HIPEXEC_E_NOMEM, "out of host memory");
+        h->helpers.push_back(g);
+        g->is_helper = true; g->device = h->device;
+        g->worker = new (std::nothrow) LaneWorker();
+        if (!g->worker) return fail(HIPEXEC_E_NOMEM, "out of host memory");
+        g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words;
+        CHK(create_lane_resources(g, h->S.n_lamp));
+        HIPCHK(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+    }
+    return HIPEXEC_OK;
+}
 
 int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_t *d_ids)
 {
@@ -1076,8 +1113,10 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
     // tiles k, k + L, ... of the call's tile list; at least 4 tiles per lane.
     const bool bounces = c->mode == HIPEXEC_MODE_CPU && c->max_depth > 0;
     const int n_window = std::min(n_tiles_of(c), h->win_hi) - h->win_lo;
-    const int L = std::min({(int)h->helpers.size() + 1, h->max_lanes, n_window / 4});
+    int L = std::min(h->max_lanes, n_window / 4);
     if (!h->use_bvh || !bounces || L < 2) return render_sub(h, c, d_rgba, d_ids, 0, 1);
+    CHK(more_lanes(h, L));
+    L = std::min(L, (int)h->helpers.size() + 1);
     h->lanes_used = L;
     // fork: the other lanes' streams start after everything queued on this executor's stream so far
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
@@ -1088,6 +1127,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
         g->win_lo = h->win_lo; g->win_hi = h->win_hi;
         for (int q = 0; q < 4; q++) g->rect[q] = h->rect[q];
         g->predict_now = h->predict_now;
+        g->block64_below = h->block64_below;
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
         g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
         g->worker->submit([&, g, k]() {
@@ -1176,17 +1216,21 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     if (const char *e = getenv("HIPEXEC_SHADOW_PER_BLOCK")) h->shadow_per_block = (uint32_t)std::max(64, std::min(256, atoi(e) / 64 * 64));
     if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("HIPEXEC_BLOCK_CLOSEST")) h->block_closest = atoi(e);
+    if (const char *e = getenv("HIPEXEC_BLOCK_SHADOW")) h->block_shadow = atoi(e);
+    if (const char *e = getenv("HIPEXEC_BLOCK_TAIL")) h->block_tail = atoi(e);
+    if (const char *e = getenv("HIPEXEC_BLOCK64_BELOW")) h->block64_below = (uint32_t)strtoul(e, nullptr, 10);
     h->n_cnt32 = std::max(8u, n_lamp + 1u);
     HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&h->d_cnt64, N_CNT64 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&h->d_cnt64, CNT64_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&h->d_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc((void **)&h->h_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), hipHostMallocDefault));
     if (const char *e = getenv("HIPEXEC_PREDICT")) h->predict = atoi(e) != 0;
     if (const char *e = getenv("HIPEXEC_PREDICT_SPOIL")) h->predict_spoil = atoi(e);   // test hook, see level_end
     HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_cnt64, N_CNT64 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_cnt64, CNT64_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, N_CNT64 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_cnt64, 0, CNT64_WORDS * sizeof(unsigned long long), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return HIPEXEC_OK;
 }
@@ -1249,17 +1293,9 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
         if (const char *e = getenv("HIPEXEC_LANES")) h->max_lanes = std::max(1, std::min(8, atoi(e)));      // 1: no further lanes
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int k = 1; h->bvh_ok && k < h->max_lanes; k++) {
-            hipexec *g = new (std::nothrow) hipexec();
-            if (!g) return fail(HIPEXEC_E_NOMEM, "out of host memory");
-            h->helpers.push_back(g);
-            g->is_helper = true; g->device = device;
-            g->worker = new (std::nothrow) LaneWorker();
-            if (!g->worker) return fail(HIPEXEC_E_NOMEM, "out of host memory");
-            g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words;     // the scene stays owned by h
-            CHK(create_lane_resources(g, scene->n_lamp));
-            HIPCHK(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
-        }
+        // (further lanes are made by the first frame that uses them, see more_lanes: streams are bound to the
+        // process's few hardware queues in the order they are created, and an executor that is used with one lane,
+        // as one of several with frames in flight, should not take queues it never uses)
         return HIPEXEC_OK;
     }();
     if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
@@ -1302,6 +1338,14 @@ int hipexec_set_stream(hipexec_t *h, void *stream)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    return HIPEXEC_OK;
+}
+
+int hipexec_set_lanes(hipexec_t *h, int lanes)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (lanes < 1 || lanes > 8) return fail(HIPEXEC_E_INVALID, "lanes %d outside [1,8]", lanes);
+    h->max_lanes = lanes;
     return HIPEXEC_OK;
 }
 

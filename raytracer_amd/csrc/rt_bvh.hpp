@@ -327,7 +327,7 @@ DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
 
 // One inner-node step of a lane: the four slot boxes of record N against the ray, the nearest hit slot
 // becomes the lane's node, the others go on its stack (farthest first).
-template <bool UNIFORM, bool SORT = true>
+template <bool UNIFORM, bool SORT = true, int BS = 256>
 DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__ N, float limit, uint32_t *stk, uint32_t &node, int &sp,
                         uint32_t &overflow)
 {
@@ -351,13 +351,13 @@ DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__
             if (hk[k]) {
                 const uint32_t ref = __float_as_uint(hi[k].w);
                 if (nxt == BVH_NONE) nxt = ref;
-                else if (sp < B.stack_limit) { stk[256 * sp] = ref; sp++; }
+                else if (sp < B.stack_limit) { stk[BS * sp] = ref; sp++; }
                 else overflow = 1u;
             }
         }
         if (overflow) node = BVH_NONE;
         else if (nxt != BVH_NONE) node = nxt;
-        else if (sp > 0) { sp--; node = stk[256 * sp]; }
+        else if (sp > 0) { sp--; node = stk[BS * sp]; }
         else node = BVH_NONE;
         return;
     }
@@ -372,13 +372,13 @@ DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__
 #pragma unroll
     for (int k = 3; k >= 1; k--) {
         if (ref[k] != BVH_NONE) {
-            if (sp < B.stack_limit) { stk[256 * sp] = ref[k]; sp++; }
+            if (sp < B.stack_limit) { stk[BS * sp] = ref[k]; sp++; }
             else overflow = 1u;
         }
     }
     if (overflow) node = BVH_NONE;
     else if (ref[0] != BVH_NONE) node = ref[0];
-    else if (sp > 0) { sp--; node = stk[256 * sp]; }
+    else if (sp > 0) { sp--; node = stk[BS * sp]; }
     else node = BVH_NONE;
 }
 
@@ -397,7 +397,7 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
 // the inner-node step (four box tests, push/pop) or the leaf step (exact tests).  Lanes waiting for
 // the other kind sit the iteration out.  (`sched` = 0 selects the classic while-while order instead:
 // inner nodes until no lane has one, then leaves.)
-template <int MODE, bool ANY>
+template <int MODE, bool ANY, int BS = 256>
 DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &best, uint32_t *stk, int min_active,
                    uint32_t &n_nodes, uint32_t &n_tris, int sched = 8, const float4 *__restrict__ nodes_sc = nullptr)
 {
@@ -423,10 +423,10 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             const bool uniform = nodes_sc != nullptr && __ballot(at_inner && node == lead_node) == m_inner;
             if (uniform) {
                 const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)lead_node);
-                if (at_inner) { n_nodes++; bvh_inner_step<true, !ANY>(B, r, nodes_sc + 9 * (size_t)un, limit, stk, node, sp, overflow); }
+                if (at_inner) { n_nodes++; bvh_inner_step<true, !ANY, BS>(B, r, nodes_sc + 9 * (size_t)un, limit, stk, node, sp, overflow); }
             } else if (at_inner) {
                 n_nodes++;
-                bvh_inner_step<false, !ANY>(B, r, B.nodes + 9 * (size_t)node, limit, stk, node, sp, overflow);
+                bvh_inner_step<false, !ANY, BS>(B, r, B.nodes + 9 * (size_t)node, limit, stk, node, sp, overflow);
             }
         } else if (at_leaf) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
@@ -452,7 +452,7 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
                 }
             }
             if (ANY && found) node = BVH_NONE;
-            else if (sp > 0) { sp--; node = stk[256 * sp]; }
+            else if (sp > 0) { sp--; node = stk[BS * sp]; }
             else node = BVH_NONE;
         }
     }
@@ -595,15 +595,15 @@ DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float 
 
 // One ray per lane, start to finish.  ANY = false: closest triangle hit into `best` (limit =
 // largest t still of interest, e.g. the sphere winner).  ANY = true: returns whether any triangle
-// is hit.  `stk` points at this lane's column of the LDS stack (entries 256 words apart).
-template <int MODE, bool ANY>
+// is hit.  `stk` points at this lane's column of the LDS stack (entries BS words apart, BS = threads per block).
+template <int MODE, bool ANY, int BS = 256>
 DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Best &best, uint32_t *stk,
                       uint32_t &n_nodes, uint32_t &n_tris, const float4 *__restrict__ nodes_sc = nullptr)
 {
     TState st; st.node = B.root; st.sp = 0; st.limit = limit; st.found = 0u; st.overflow = 0u;
     // step scheduling weight 16: the wave takes the leaf step unless twice as many lanes wait for an inner-node step
     // (a leaf step is what ends rays and shrinks limits; measured against 8, plain majority: C2 -2 %, C3 -2.5 %)
-    bvh_burst<MODE, ANY>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, 16, nodes_sc);
+    bvh_burst<MODE, ANY, BS>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, 16, nodes_sc);
     if (st.overflow) {
         n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
         st.found = bvh_linear<MODE, ANY>(B, o, d, best, n_tris) ? 1u : 0u;
@@ -744,6 +744,8 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // blocks add to one of CNT_STRIPES copies of the counters (atomics on one address are serialised by the L2)
+        counters += (size_t)(blockIdx.x & (CNT_STRIPES - 1u)) * CNT_STRIDE;
         if (block_sum[0]) atomicAdd(&counters[8 + klass], block_sum[0]);
         if (block_sum[1]) atomicAdd(&counters[11 + klass], block_sum[1]);
         if (block_sum[2]) atomicAdd(&counters[15], block_sum[2]);
@@ -751,14 +753,16 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+// BS = threads per block.  A block's LDS (its stacks) is released only when its last wave has finished, and rays
+// differ widely in length: with one wave per block no finished wave keeps memory from a waiting block.
+template <int MODE, int BS>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                      float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                      int klass, const uint32_t *__restrict__ n_dev)
 {
-    __shared__ uint32_t stack[BVH_STACK][256];
+    __shared__ uint32_t stack[BVH_STACK][BS];
     n = queue_fill(n, n_dev);
-    uint32_t j = xcd_block() * 256u + threadIdx.x;
+    uint32_t j = xcd_block() * (uint32_t)BS + threadIdx.x;
     bool valid = j < n;
     f3 o, d; uint32_t s, aux;
     load_ray(rays, valid ? j : 0u, o, d, s, aux);
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
         Best tb = best_none();
         TRay r = tray_make(S, B, o, d);
         float limit = sb.id >= 0 ? sb.t : __builtin_inff();
-        bvh_traverse<MODE, false>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris);
+        bvh_traverse<MODE, false, BS>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris);
         hits[j] = merge_hits<MODE>(S, tb, sb);
     }
     bvh_count(counters, klass, n_nodes, n_tris, 0u);
@@ -982,8 +986,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // to one lamp after the other; lanes whose sample casts no ray to the lamp at hand sit that lamp out.  No barriers and
 // no LDS besides the stacks, but the waves are only as full as the fraction of samples that face the lamp.
 // ---------------------------------------------------------------------------------------
-template <int MODE, bool FUSED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
+template <int MODE, bool FUSED, int BS>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
                                                     uint32_t *__restrict__ occl, uint32_t lw,
                                                     unsigned long long *__restrict__ counters, uint32_t per_block,
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                                                     const uint32_t *__restrict__ n_dev)
 {
     n = queue_fill(n, n_dev);
-    __shared__ uint32_t stack[BVH_STACK][256];
+    __shared__ uint32_t stack[BVH_STACK][BS];
     // The spheres are tested one after the other for every shadow ray, each test behind a load of its own: from LDS
     // that load takes a tenth of the time it takes from the vector cache (first SPH_LDS spheres; the rest from memory).
     // C5 (16 spheres) -2.5 %; the closest-hit kernels test the spheres once per ray and gain nothing from the same copy.
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
             if (!occluded) {
                 TRay r = tray_make(S, B, P, toLamp);
                 Best none = best_none();
-                occluded = bvh_traverse<MODE, true>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris, nodes_sc);
+                occluded = bvh_traverse<MODE, true, BS>(B, r, P, toLamp, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris, nodes_sc);
             }
             if (occluded) {
                 if (FUSED) occ_bits |= 1u << l;
@@ -1067,15 +1071,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // sample, hence the same bits as the level-by-level kernels.
 // counters[16] += bounce rays generated here (levels above level0).
 // ---------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_tail(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n, int level0,
+template <int MODE, int BS>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_tail(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n, int level0,
                                                   int depth, float4 *__restrict__ local, size_t level_stride,
                                                   unsigned long long *__restrict__ counters, const uint32_t *__restrict__ n_dev)
 {
-    __shared__ uint32_t stack[BVH_STACK][256];
+    __shared__ uint32_t stack[BVH_STACK][BS];
     n = queue_fill(n, n_dev);
     uint32_t *stk = &stack[0][threadIdx.x];
-    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    uint32_t j = blockIdx.x * (uint32_t)BS + threadIdx.x;
     bool alive = j < n;
     f3 o, d; uint32_t s, aux;
     load_ray(rays, alive ? j : 0u, o, d, s, aux);
@@ -1084,7 +1088,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         Best sb = spheres_closest<MODE>(S, o, d);
         Best tb = best_none();
         TRay r = tray_make(S, B, o, d);
-        bvh_traverse<MODE, false>(B, r, o, d, sb.id >= 0 ? sb.t : __builtin_inff(), tb, stk, nodes_c, tris_c);
+        bvh_traverse<MODE, false, BS>(B, r, o, d, sb.id >= 0 ? sb.t : __builtin_inff(), tb, stk, nodes_c, tris_c);
         float4 h = merge_hits<MODE>(S, tb, sb);
         f3 ret; float w = -1.0f;
         if (__float_as_int(h.w) < 0) {
@@ -1110,7 +1114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                 if (!occluded) {
                     TRay rs = tray_make(S, B, sf.P, toLamp);
                     Best none = best_none();
-                    occluded = bvh_traverse<MODE, true>(B, rs, sf.P, toLamp, __builtin_inff(), none, stk, nodes_s, tris_s);
+                    occluded = bvh_traverse<MODE, true, BS>(B, rs, sf.P, toLamp, __builtin_inff(), none, stk, nodes_s, tris_s);
                 }
                 if (occluded) continue;
                 ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
@@ -1128,7 +1132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     __syncthreads();                        // bvh_count's LDS sums are reused by the second call
     bvh_count(counters, 2, nodes_s, tris_s, n_shadow);
     unsigned long long nb = wave_sum_u64(n_bounce);
-    if ((threadIdx.x & 63u) == 0 && nb) atomicAdd(&counters[16], nb);
+    if ((threadIdx.x & 63u) == 0 && nb) atomicAdd(&counters[(size_t)(blockIdx.x & (CNT_STRIPES - 1u)) * CNT_STRIDE + 16], nb);
 }
 
 }  // namespace rt

@@ -42,7 +42,9 @@ DEV f3 xyz(float4 a) { return mk(a.x, a.y, a.z); }
 
 // Scene in device memory.  Triangle arrays are padded to a multiple of TRI_PAD records with
 // records no ray can hit.
-constexpr int TRI_PAD = 128;   // = 2 * LDS_CHUNK triangles: whole LDS chunks of triangle pairs
+constexpr int TRI_PAD = 128;
+// The 64-bit work counters of a call exist in CNT_STRIPES copies of CNT_STRIDE words; the host adds the copies up.
+constexpr uint32_t CNT_STRIPES = 64, CNT_STRIDE = 32;   // = 2 * LDS_CHUNK triangles: whole LDS chunks of triangle pairs
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -416,7 +418,7 @@ DEV uint32_t wave_append(bool pred, uint32_t *counter) {
 
 // The same for a whole 256-thread block: one global atomic per block instead of one per wave
 // (atomics on a single address are serialised by the L2; at one per wave they bound k_shade).
-// Every thread of the block must call this; `scratch` is 5 words of LDS.
+// Every thread of the block (64 to 256 threads) must call this; `scratch` is 5 words of LDS.
 DEV uint32_t block_append(bool pred, uint32_t *counter, uint32_t *scratch) {
     unsigned long long m = __ballot(pred);
     int lane = lane_id();
@@ -424,7 +426,8 @@ DEV uint32_t block_append(bool pred, uint32_t *counter, uint32_t *scratch) {
     if (lane == 0) scratch[w] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < (blockDim.x >> 6); k++) total += scratch[k];
         scratch[4] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();

@@ -66,6 +66,10 @@ class HipExecutor:
     def sync(self):
         self._check(self._lib.hipexec_sync(self._h))
 
+    def set_lanes(self, lanes: int):
+        """Concurrent lanes a frame is spread over (default 2); 1 for executors that alternate frames (FramesInFlight)."""
+        self._check(self._lib.hipexec_set_lanes(self._h, int(lanes)))
+
     # -- frame ----------------------------------------------------------------------------
     @staticmethod
     def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo=None, bilinear=False):
@@ -168,3 +172,49 @@ class HipExecutor:
         self._check(self._lib.hipexec_trace_rays(self._h, int(mode), int(max_depth), r.ctypes.data, r.shape[0],
                                                  colours.ctypes.data, C.byref(st)))
         return (colours, st) if want_stats else colours
+
+
+class FramesInFlight:
+    """Throughput mode: `depth` executors of one scene, one lane each, take device-resident frames in turn.
+
+    submit() enqueues a frame (asynchronous) on the next executor and returns the slot it used; collect(slot) waits
+    for that frame and returns its Stats.  A slot must be collected before submit() reaches it again; submit() does it
+    itself if the caller has not.  With depth 2 the thinly populated deep recursion levels of one frame run beside the
+    camera and first-bounce launches of the next.  The frames are the ones a single executor renders, bit for bit."""
+
+    def __init__(self, scene: FlatScene, device: int = -1, depth: int = 2):
+        self.ex = [HipExecutor(scene, device=device) for _ in range(depth)]
+        for e in self.ex:
+            e.set_lanes(1 if depth > 1 else 2)
+        self.stats = [_abi.Stats() for _ in range(depth)]
+        self.busy = [False] * depth
+        self.next = 0
+
+    def submit(self, width, height, d_out_rgba: int, d_out_ids: int | None = None, **kw) -> int:
+        k = self.next
+        self.next = (k + 1) % len(self.ex)
+        if self.busy[k]:
+            self.collect(k)
+        self.ex[k].render_device(width, height, d_out_rgba, d_out_ids, stats=self.stats[k], **kw)
+        self.busy[k] = True
+        return k
+
+    def collect(self, slot: int):
+        if self.busy[slot]:
+            self.ex[slot].sync()
+            self.busy[slot] = False
+        return self.stats[slot]
+
+    def drain(self):
+        for k in range(len(self.ex)):
+            self.collect(k)
+
+    def close(self):
+        for e in self.ex:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

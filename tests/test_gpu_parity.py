@@ -412,3 +412,47 @@ def test_remembered_queue_sizes(monkeypatch, spoil):
                 assert st.rays == ref["stats"].rays
     finally:
         hip.free(d_out)
+
+
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_frames_in_flight_equal_single_frames(in_flight):
+    """Throughput mode: executors of one scene, one lane each, take asynchronous device-resident frames in turn.  Every
+    frame is the oracle's (ids exact through the colours' parity, linear colour within 4 ULP), whatever is in flight
+    beside it: frames of two different sizes and depths alternate."""
+    from raytracer_amd.executor import FramesInFlight
+    from oracle.binding import Oracle
+    from tests.util import HipMem
+    fs = scenegen.small_variant("mirror").to_flat()
+    cfgs = [(48, 132, 4), (64, 40, 1)]
+    refs = [Oracle(fs).render(W, H, mode=CPU, max_depth=d, tone=0, n_threads=8) for (W, H, d) in cfgs]
+    hip = HipMem()
+    size = max(((H + 7) // 8) * 8 * W * 16 for (W, H, _) in cfgs)
+    bufs = [hip.malloc(size) for _ in range(in_flight)]
+    try:
+        with FramesInFlight(fs, device=0, depth=in_flight) as pipe:
+            pending = []                                     # (slot, cfg index)
+            done = 0
+
+            def check(slot, ci):
+                W, H, d = cfgs[ci]
+                st = pipe.collect(slot)
+                out = np.zeros((((H + 7) // 8) * 8, W, 4), np.float32)
+                hip.d2h(out, bufs[slot])
+                assert ulp_diff(out[:H, :, :3], refs[ci]["linear"]).max() <= 4
+                assert (out[:H, :, 3] == 1).all()
+                assert st.rays == refs[ci]["stats"].rays and st.lanes == 1
+            for i in range(9):
+                ci = i % 2
+                W, H, d = cfgs[ci]
+                if len(pending) == in_flight:
+                    check(*pending.pop(0)); done += 1
+                k = pipe.next
+                hip.memset(bufs[k], 0, size)
+                hip.sync()
+                pending.append((pipe.submit(W, H, bufs[k], None, mode=CPU, max_depth=d, tone=False), ci))
+            while pending:
+                check(*pending.pop(0)); done += 1
+            assert done == 9
+    finally:
+        for b in bufs:
+            hip.free(b)
