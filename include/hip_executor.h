@@ -94,6 +94,11 @@ typedef struct hipexec_scene_desc {
     float cam_mat[9];          /* cam_mat[3*i+c] = JSON transform[i][c]; world[i] = sum_c cam_mat[3*i+c]*cam[c] */
     float horizon[3];          /* worldHorizonColor                                         */
     float ambient[3];          /* worldAmbientColor                                         */
+    /* The two Material fields the reference declares but never loads or reads (scene.h:28-29); both may be NULL
+     * (= all zero).  Only HIPEXEC_FLAG_REFRACT looks at them. */
+    const float   *mat_kt;     /* [n_mat]  refractionFactor: weight of the refracted ray's colour            */
+    const float   *mat_ior;    /* [n_mat]  refractionHardness, taken as the relative index of refraction
+                                           (values <= 0 count as 1)                                          */
 } hipexec_scene_desc;
 
 /* Run-time counterpart of the compile-time knobs of config.h:8-20. */
@@ -126,11 +131,21 @@ typedef struct hipexec_render_cfg {
                                          (u - 0.5, v - 0.5) instead of taking tex_image::get's single texel
                                          (tex_image.h:34-44).  Frame entry points only.                     */
 
+#define HIPEXEC_FLAG_REFRACT      16   /* NOT a reference mode (the reference has no refraction, only the two unused Material
+                                         fields of scene.h:28-29): in HIPEXEC_MODE_CPU with max_depth > 0 a hit on a material
+                                         with refractionFactor > EPS continues with the REFRACTED ray instead of the mirrored
+                                         one, weighted by refractionFactor.  With i = d/|d|, N the stored normal, n the
+                                         material's index: entering if dot(i,N) < 0 (eta = 1/n, normal N) else leaving
+                                         (eta = n, normal -N); k = 1 - eta^2 (1 - cos^2); k < 0 is total internal reflection
+                                         and takes the mirrored direction d - 2N(d.N), otherwise the direction is
+                                         eta*i + (eta*cos - sqrt(k))*normal.  Shadow rays are unchanged (transmissive
+                                         objects still cast full shadows).  Frame entry points only.                    */
+
 /* Both algorithms evaluate the same exact ray/primitive arithmetic and return identical hits and
  * colours; they differ in which tests they can prove unnecessary. */
 enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };
 
-#define HIPEXEC_ABI_VERSION 3
+#define HIPEXEC_ABI_VERSION 4
 
 /* Kernel classes reported in hipexec_stats. */
 enum {

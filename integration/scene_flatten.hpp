@@ -25,7 +25,7 @@ public:
 
 private:
     std::vector<float> tri_p_, tri_e1_, tri_e2_, tri_norm_, tri_uv_, sph_c_, sph_r_;
-    std::vector<float> mat_color_, mat_kd_, mat_ks_, mat_hard_, mat_kr_, lamp_pos_, lamp_i_, lamp_d_;
+    std::vector<float> mat_color_, mat_kd_, mat_ks_, mat_hard_, mat_kr_, mat_kt_, mat_ior_, lamp_pos_, lamp_i_, lamp_d_;
     std::vector<int32_t> tri_mat_, sph_mat_, mat_tex_;
     std::vector<uint8_t> tex_rgba_;
     std::vector<uint64_t> tex_off_;
@@ -46,6 +46,7 @@ private:
         mat_color_.push_back(m->color.x); mat_color_.push_back(m->color.y); mat_color_.push_back(m->color.z);
         mat_kd_.push_back(m->diffusiveFactor); mat_ks_.push_back(m->specularFactor);
         mat_hard_.push_back(m->specularHardness); mat_kr_.push_back(m->reflectionFactor);
+        mat_kt_.push_back(m->refractionFactor); mat_ior_.push_back(m->refractionHardness);      // scene.h:28-29 (0 unless a caller sets them)
         int32_t tex = -1;
         if (m->textured && m->texImage) {                 // tex_image.h:13-69: RGBA8 rows top-down
             auto tt = tex_index_.find(static_cast<const void *>(m->texImage.get()));
@@ -86,6 +87,7 @@ private:
         d_.n_mat = (uint32_t)mat_kd_.size();
         d_.mat_color = mat_color_.data(); d_.mat_kd = mat_kd_.data(); d_.mat_ks = mat_ks_.data();
         d_.mat_hard = mat_hard_.data(); d_.mat_kr = mat_kr_.data(); d_.mat_tex = mat_tex_.data();
+        d_.mat_kt = mat_kt_.data(); d_.mat_ior = mat_ior_.data();
         d_.n_tex = (uint32_t)tex_w_.size();
         d_.tex_rgba = tex_rgba_.data(); d_.tex_offset = tex_off_.data(); d_.tex_w = tex_w_.data(); d_.tex_h = tex_h_.data();
         d_.n_lamp = (uint32_t)lamp_i_.size();

@@ -209,6 +209,7 @@ void orc_tex_bilinear(const hipexec_scene_desc *s, int tex, float ux, float uy, 
 }
 
 static __thread int tl_bilinear = 0;      /* set per worker thread from hipexec_render_cfg.flags */
+static __thread int tl_refract = 0;       /* likewise: HIPEXEC_FLAG_REFRACT */
 
 /* (unsigned int) of a float as x86-64 gcc evaluates it: truncate to a 64-bit integer, keep
  * the low 32 bits (ray_tracer.cpp:236-237).  Out-of-range and NaN give 0 like cvttss2si. */
@@ -219,15 +220,17 @@ static unsigned f2u_x86(float f)
 }
 
 /* ---- materials ------------------------------------------------------------------------ */
-typedef struct { v3 color; float kd, ks, hard, kr; int tex; } mat_t;
+typedef struct { v3 color; float kd, ks, hard, kr, kt, ior; int tex; } mat_t;
 
 static mat_t get_mat(const hipexec_scene_desc *s, int m)
 {
-    mat_t r; r.color = V(0, 0, 0); r.kd = r.ks = r.hard = r.kr = 0.0f; r.tex = -1;   /* scene.h:32-44 */
+    mat_t r; r.color = V(0, 0, 0); r.kd = r.ks = r.hard = r.kr = r.kt = r.ior = 0.0f; r.tex = -1;   /* scene.h:32-44 */
     if (m >= 0 && (uint32_t)m < s->n_mat) {
         r.color = ld3(s->mat_color + 3 * m);
         r.kd = s->mat_kd[m]; r.ks = s->mat_ks[m]; r.hard = s->mat_hard[m]; r.kr = s->mat_kr[m];
         r.tex = s->mat_tex ? s->mat_tex[m] : -1;
+        r.kt = s->mat_kt ? s->mat_kt[m] : 0.0f;              /* scene.h:28-29: declared, never loaded by the reference */
+        r.ior = s->mat_ior ? s->mat_ior[m] : 0.0f;
     }
     return r;
 }
@@ -380,7 +383,23 @@ static v3 trace_cpu(const hipexec_scene_desc *s, v3 o, v3 d, int depth, int max_
             ret = add(ret, muls(muls(hit.color, m.ks), phong));
         }
     }
-    if (max_depth > 0 && (double)m.kr > EPS && depth < max_depth) {
+    if (tl_refract && max_depth > 0 && (double)m.kt > EPS && depth < max_depth) {
+        /* HIPEXEC_FLAG_REFRACT (NOT reference behaviour; definition in include/hip_executor.h): the secondary ray of a
+         * transmissive material is the refracted one, or the mirrored one under total internal reflection. */
+        float n = m.ior > 0.0f ? m.ior : 1.0f;
+        float dl = sqrtf(dot(d, d));
+        v3 i = muls(d, 1.0f / dl);
+        float c = dot(i, hit.norm);
+        int entering = c < 0.0f;
+        v3 nf = entering ? hit.norm : neg(hit.norm);
+        float eta = entering ? 1.0f / n : n;
+        float cosi = entering ? -c : c;
+        float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+        v3 rd;
+        if (k < 0.0f) rd = sub(d, muls(smul(2.0f, hit.norm), dot(d, hit.norm)));
+        else rd = add(muls(i, eta), muls(nf, eta * cosi - sqrtf(k)));
+        ret = add(ret, muls(trace_cpu(s, hit.point, rd, depth + 1, max_depth, st, NULL), m.kt));
+    } else if (max_depth > 0 && (double)m.kr > EPS && depth < max_depth) {
         v3 rd = sub(d, muls(smul(2.0f, hit.norm), dot(d, hit.norm)));
         ret = add(ret, muls(trace_cpu(s, hit.point, rd, depth + 1, max_depth, st, NULL), m.kr));
     }
@@ -450,6 +469,7 @@ static void render_block(const job_t *J, int bx, int by, int bw, int bh, hipexec
     int width = J->cfg->width, height = J->cfg->height;
     int cl = (J->cfg->mode == HIPEXEC_MODE_CL);
     tl_bilinear = (J->cfg->flags & HIPEXEC_FLAG_BILINEAR) != 0;
+    tl_refract = (J->cfg->flags & HIPEXEC_FLAG_REFRACT) != 0;
     int spp = cl ? 1 : 4;
     float camHeight = 0.5;
     float camWidth = (float)width * (camHeight / (float)height);

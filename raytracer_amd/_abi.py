@@ -15,9 +15,10 @@ HIPEXEC_K_PRIMARY, HIPEXEC_K_CLOSEST, HIPEXEC_K_ANYHIT, HIPEXEC_K_SHADE = 0, 1, 
 HIPEXEC_FLAG_SCAN = 2
 HIPEXEC_FLAG_BVH = 4
 HIPEXEC_FLAG_BILINEAR = 8
+HIPEXEC_FLAG_REFRACT = 16
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATIC_MAX_RAYS = 1 << 18
 
 _fp = C.POINTER(C.c_float)
@@ -36,6 +37,7 @@ class SceneDesc(C.Structure):
         ("n_lamp", C.c_uint32), ("lamp_pos", _fp), ("lamp_intensity", _fp), ("lamp_distance", _fp),
         ("cam_pos", C.c_float * 3), ("cam_mat", C.c_float * 9),
         ("horizon", C.c_float * 3), ("ambient", C.c_float * 3),
+        ("mat_kt", _fp), ("mat_ior", _fp),
     ]
 
 

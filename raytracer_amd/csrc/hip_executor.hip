@@ -483,6 +483,12 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     float4 *d_ma = nullptr, *d_mb = nullptr;
     CHK(upload(h, ma.data(), ma.size(), &d_ma)); CHK(upload(h, mb.data(), mb.size(), &d_mb));
     S.mat_a = d_ma; S.mat_b = d_mb;
+    // the two Material fields the reference never reads (scene.h:28-29), for the optional refraction mode
+    std::vector<float2> mc(s->n_mat + 1, make_float2(0.f, 0.f));
+    for (uint32_t i = 0; i < s->n_mat; i++) mc[i] = make_float2(s->mat_kt ? s->mat_kt[i] : 0.f, s->mat_ior ? s->mat_ior[i] : 0.f);
+    float2 *d_mc = nullptr;
+    CHK(upload(h, mc.data(), mc.size(), &d_mc));
+    S.mat_c = d_mc;
 
     // textures
     uint64_t tex_bytes = 0;
@@ -550,6 +556,7 @@ int call_begin(hipexec *h, uint32_t timing, uint32_t flags)
     bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
     h->use_bvh = want_bvh && h->bvh_ok;
     h->S.bilinear = (flags & HIPEXEC_FLAG_BILINEAR) ? 1u : 0u;
+    h->S.refract = (flags & HIPEXEC_FLAG_REFRACT) ? 1u : 0u;
     if (h->call_open) {   // a previous asynchronous call has not been collected yet (or failed half-way)
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->side) HIPCHK(hipStreamSynchronize(h->side));
@@ -1070,7 +1077,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         int levels_used = 1;
         const std::array<int64_t, 24> key = {1, c->width, c->height, MODE, depth, c->tile_first, c->tile_step, h->win_lo, h->win_hi,
                                              cx0, cy0, cx1, cy1, sub, n_sub, t0, (int64_t)n0, h->use_bvh, h->tail_max, h->overlap_levels,
-                                             h->bvh_refill, h->fuse_shade, (int64_t)h->simple_from, 0};
+                                             h->bvh_refill, h->fuse_shade, (int64_t)h->simple_from, (int64_t)h->S.refract};
         CHK(trace_levels<MODE>(h, (uint32_t)n0, (size_t)n0, depth, &levels_used, key));
         LAUNCH(HIPEXEC_K_SHADE, (k_resolve<MODE>), blocks_for(F.n_slots), F, h->local.as<float4>(), (size_t)n0, levels_used,
                h->hit0.as<float4>(), c->tone, d_rgba, d_ids);
@@ -1134,7 +1141,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
             rcs[(size_t)k] = [&]() -> int {
                 HIPCHK(hipSetDevice(g->device));
                 HIPCHK(hipStreamWaitEvent(g->stream, h->ev_fork, 0));
-                CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & HIPEXEC_FLAG_BILINEAR)));
+                CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & (HIPEXEC_FLAG_BILINEAR | HIPEXEC_FLAG_REFRACT))));
                 return render_sub(g, c, d_rgba, d_ids, k, L);
             }();
             if (rcs[(size_t)k] != HIPEXEC_OK) errs[(size_t)k] = g_err;          // g_err is per thread

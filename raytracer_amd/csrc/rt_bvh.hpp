@@ -1119,12 +1119,11 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 if (occluded) continue;
                 ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
             }
-            if (MODE == HIPEXEC_MODE_CPU && level < depth && sf.kr > RT_EPSF) {
-                w = sf.kr;
-                f3 bd = d - 2.0f * sf.N * dot(d, sf.N);
+            f3 bd;
+            if (MODE == HIPEXEC_MODE_CPU && level < depth && secondary_ray(S, sf.mat, sf.kr, d, sf.N, w, bd)) {
                 o = sf.P; d = bd;
                 n_bounce++;
-            } else alive = false;
+            } else { w = -1.0f; alive = false; }
         }
         local[(size_t)level * level_stride + s] = make_float4(ret.x, ret.y, ret.z, w);
     }

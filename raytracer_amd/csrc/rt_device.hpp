@@ -85,6 +85,8 @@ struct DScene {
     const float4 *chunk_box;
     uint32_t cull;           // 1: skip chunks no ray of the wave can hit; 0: scan every chunk
     uint32_t bilinear;       // 1: HIPEXEC_FLAG_BILINEAR for this call (not a reference mode)
+    uint32_t refract;        // 1: HIPEXEC_FLAG_REFRACT for this call (not a reference mode)
+    const float2 *mat_c;     // {refractionFactor, refractionHardness = index of refraction}   [n_mat + 1]
     const float *tri_norm;   // [n][3]
     const float *tri_uv;     // [n][6]
     const int *tri_mat;      // [n]  (index n_mat = default material)
@@ -290,6 +292,12 @@ DEV float4 merge_hits(const DScene &S, const Best &tb, const Best &sb) {
 // ---------------------------------------------------------------------------------------
 struct Surf { f3 P, N, color; float kd, ks, hard, kr; int mat; };
 
+// Secondary ray of a hit on a surface with normal N: the mirrored ray of ray_tracer.cpp:190-196 (weight
+// reflectionFactor kr, direction d - 2N(d.N), not re-normalised), or, with HIPEXEC_FLAG_REFRACT on a material whose
+// refractionFactor kt exceeds EPS, the refracted ray as include/hip_executor.h defines it (weight kt).  Returns false
+// if the path ends here.
+DEV bool secondary_ray(const DScene &S, int mat, float kr, f3 d, f3 N, float &w, f3 &bd);
+
 // (unsigned int) of a float the way x86-64 gcc evaluates it (truncate to 64-bit, keep the low
 // 32 bits): ray_tracer.cpp:236-237
 DEV uint32_t f2u_x86(float f) {
@@ -359,6 +367,33 @@ DEV Surf surface(const DScene &S, f3 o, f3 d, float4 h, bool want_color) {
         r.color = c.w * mk(c.x, c.y, c.z) + (1 - c.w) * xyz(ma);
     }
     return r;
+}
+
+DEV bool secondary_ray(const DScene &S, int mat, float kr, f3 d, f3 N, float &w, f3 &bd) {
+    if (S.refract) {
+        float2 c2 = S.mat_c[mat];
+        if (c2.x > 0.0001f) {            // RT_EPSF
+            float n = c2.y > 0.0f ? c2.y : 1.0f;
+            float dl = sqrtf(dot(d, d));
+            f3 i = d * (1.0f / dl);
+            float c = dot(i, N);
+            bool entering = c < 0.0f;
+            f3 nf = entering ? N : -N;
+            float eta = entering ? 1.0f / n : n;
+            float cosi = entering ? -c : c;
+            float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+            if (k < 0.0f) bd = d - 2.0f * N * dot(d, N);
+            else bd = i * eta + nf * (eta * cosi - sqrtf(k));
+            w = c2.x;
+            return true;
+        }
+    }
+    if (kr > 0.0001f) {
+        w = kr;
+        bd = d - 2.0f * N * dot(d, N);
+        return true;
+    }
+    return false;
 }
 
 // powf(x, y) of the shading code.  Evaluated in double and rounded once: correctly rounded

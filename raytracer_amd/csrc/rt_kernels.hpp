@@ -902,10 +902,9 @@ DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *o
             if (occ[l >> 5] & (1u << (l & 31u))) continue;
             ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
         }
-        if (MODE == HIPEXEC_MODE_CPU && spawn && sf.kr > RT_EPSF) {
-            bounce = true; w = sf.kr;
+        if (MODE == HIPEXEC_MODE_CPU && spawn && secondary_ray(S, sf.mat, sf.kr, d, sf.N, w, bd)) {
+            bounce = true;
             bo = sf.P;
-            bd = d - 2.0f * sf.N * dot(d, sf.N);
         }
     }
     return make_float4(ret.x, ret.y, ret.z, w);
@@ -962,11 +961,10 @@ __global__ __launch_bounds__(256) void k_bounce(DScene S, const float4 *__restri
     f3 bo = mk(0.f, 0.f, 0.f), bd = mk(0.f, 0.f, 1.f);
     if (valid && __float_as_int(h.w) >= 0) {
         Surf sf = surface(S, o, d, h, false);
-        float kr = S.mat_b[sf.mat].z;
-        if (MODE == HIPEXEC_MODE_CPU && kr > RT_EPSF) {
+        float kr = S.mat_b[sf.mat].z, w;
+        if (MODE == HIPEXEC_MODE_CPU && secondary_ray(S, sf.mat, kr, d, sf.N, w, bd)) {
             bounce = true;
             bo = sf.P;
-            bd = d - 2.0f * sf.N * dot(d, sf.N);
         }
     }
     __shared__ uint32_t append_scratch[5];

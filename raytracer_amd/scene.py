@@ -67,6 +67,10 @@ class FlatScene:
     mat_hard: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.float32))
     mat_kr: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.float32))
     mat_tex: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    # refractionFactor / refractionHardness (scene.h:28-29): never loaded by the reference; None = all zero.  Only the
+    # optional, non-reference refraction mode reads them (hardness = relative index of refraction).
+    mat_kt: np.ndarray | None = None
+    mat_ior: np.ndarray | None = None
     textures: list = field(default_factory=list)       # list of uint8 arrays [h][w][4], rows top-down
     lamp_pos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     lamp_intensity: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.float32))
@@ -103,6 +107,9 @@ class FlatScene:
         for k in ("mat_kd", "mat_ks", "mat_hard", "mat_kr"):
             setattr(self, k, _f32(getattr(self, k), (nm,)))
         self.mat_tex = np.ascontiguousarray(self.mat_tex, dtype=np.int32).reshape(nm)
+        for k in ("mat_kt", "mat_ior"):
+            if getattr(self, k) is not None:
+                setattr(self, k, _f32(getattr(self, k), (nm,)))
         nl = np.size(self.lamp_intensity)
         self.lamp_pos = _f32(self.lamp_pos, (nl, 3))
         self.lamp_intensity = _f32(self.lamp_intensity, (nl,)); self.lamp_distance = _f32(self.lamp_distance, (nl,))
@@ -136,6 +143,10 @@ class FlatScene:
         d.n_mat = int(self.mat_kd.shape[0])
         d.mat_color, d.mat_kd, d.mat_ks = fp(self.mat_color), fp(self.mat_kd), fp(self.mat_ks)
         d.mat_hard, d.mat_kr, d.mat_tex = fp(self.mat_hard), fp(self.mat_kr), ip(self.mat_tex)
+        if self.mat_kt is not None:
+            d.mat_kt = fp(self.mat_kt)
+        if self.mat_ior is not None:
+            d.mat_ior = fp(self.mat_ior)
         d.n_tex = len(self.textures)
         offs, ws, hs, blobs, off = [], [], [], [], 0
         for t in self.textures:

@@ -53,6 +53,9 @@ class SceneSpec:
         s.mat_ks = [m["specularFactor"] for m in self.materials]
         s.mat_hard = [m["specularHardness"] for m in self.materials]
         s.mat_kr = [m["reflectionFactor"] for m in self.materials]
+        if any(m.get("refractionFactor", 0.0) for m in self.materials):
+            s.mat_kt = _f32([m.get("refractionFactor", 0.0) for m in self.materials])
+            s.mat_ior = _f32([m.get("refractionHardness", 1.0) for m in self.materials])
         s.mat_tex = np.asarray(mtex, dtype=np.int32)
         nf = self.faces.shape[0]
         uv = self.face_uv if self.face_uv is not None else np.zeros((nf, 3, 2), np.float32)
@@ -111,10 +114,13 @@ class SceneSpec:
 
 
 # ----------------------------------------------------------------------------------------
-def material(color, kd=0.8, ks=0.5, hard=50.0, kr=0.0, texture=None, scale=(1.0, 1.0)):
+def material(color, kd=0.8, ks=0.5, hard=50.0, kr=0.0, texture=None, scale=(1.0, 1.0), kt=0.0, ior=1.0):
+    """kt / ior: refractionFactor / refractionHardness (scene.h:28-29).  The reference never loads them, so they are not
+    written to the JSON document; to_flat() passes them on for the optional refraction mode."""
     return {"diffusiveColor": [float(c) for c in color], "diffusiveFactor": float(kd), "specularFactor": float(ks),
             "specularHardness": float(hard), "reflectionFactor": float(kr),
-            "texture": texture, "scaleX": float(scale[0]), "scaleY": float(scale[1])}
+            "texture": texture, "scaleX": float(scale[0]), "scaleY": float(scale[1]),
+            "refractionFactor": float(kt), "refractionHardness": float(ior)}
 
 
 def camera(pos, pitch_deg=0.0, yaw_deg=0.0):
@@ -275,6 +281,27 @@ def scene_mirror_box(seed=7) -> SceneSpec:
                      {"ambientColor": [0.02, 0.02, 0.02], "horizonColor": [0.3, 0.3, 0.3], "ambientFactor": 0.0})
 
 
+def scene_glass(seed=11) -> SceneSpec:
+    """Mirror-box variant for the optional refraction mode: two glass spheres (one in front of the other), a glass
+    slab of two triangles, a mirror floor; rays enter and leave the glass and meet total internal reflection."""
+    rng = np.random.default_rng(seed)
+    bv, bf = box_mesh((-5, 0, -14), (5, 7, 3))
+    bf = bf[:, ::-1].copy()
+    sv = np.array([[-2.5, 0.5, -5.5], [2.5, 0.5, -5.5], [2.5, 4.5, -6.5], [-2.5, 4.5, -6.5]], np.float32)     # tilted pane
+    sf = np.array([[0, 1, 2], [0, 2, 3]], np.int64)
+    mats = [material((0.8, 0.8, 0.85), kd=0.6, ks=0.3, hard=30, kr=0.3),
+            material((0.9, 0.95, 1.0), kd=0.1, ks=0.8, hard=120, kr=0.2, kt=0.85, ior=1.5),
+            material((0.6, 0.9, 0.7), kd=0.2, ks=0.6, hard=80, kt=0.7, ior=1.33),
+            material(rng.uniform(0.2, 0.9, 3), kd=0.8, ks=0.4, hard=25)]
+    V, F, UV, HAS, M = _merge([(bv, bf, None, 0), (sv, sf, None, 2)])
+    sph = [{"center": [-1, 2, -8], "radius": 1.5, "material": 1}, {"center": [2, 1, -4], "radius": 1.0, "material": 1},
+           {"center": [1, 2, -11], "radius": 1.75, "material": 3}]
+    lamps = [{"pos": [0, 6, -2], "intensity": 1.0, "distance": 45.0}, {"pos": [-4, 5, -10], "intensity": 0.6, "distance": 35.0}]
+    T, pos = camera((0, 3, 2), pitch_deg=-6, yaw_deg=3)
+    return SceneSpec(V, F, None, None, M, mats, sph, lamps, T, pos,
+                     {"ambientColor": [0.03, 0.03, 0.03], "horizonColor": [0.3, 0.35, 0.45], "ambientFactor": 0.0})
+
+
 def scene_ties(seed=8) -> SceneSpec:
     """Adversarial ties: coplanar duplicate triangles (lowest index must win), a sphere tangent
     to a triangle plane, a face with null material, a face without UVs on a textured material,
@@ -327,6 +354,7 @@ def small_variant(name: str) -> SceneSpec:
         "c4": lambda: scene_c4(cells=12, n_tex=4, tex_size=128),
         "c5": lambda: scene_c5(cells=12, n_lamps=16, n_spheres=6),
         "mirror": scene_mirror_box,
+        "glass": scene_glass,
         "ties": scene_ties,
         "soup": scene_soup,
     }[name]()

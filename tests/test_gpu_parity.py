@@ -456,3 +456,32 @@ def test_frames_in_flight_equal_single_frames(in_flight):
     finally:
         for b in bufs:
             hip.free(b)
+
+
+@pytest.mark.parametrize("tail_max", ["0", "300000"])
+def test_refraction_mode_matches_its_cpu_definition(monkeypatch, tail_max):
+    """The optional refraction mode (no reference counterpart; the reference only declares the two Material fields,
+    scene.h:28-29) against the oracle's definition: glass spheres and a glass pane, rays entering, leaving and totally
+    reflected inside; both algorithms, level-by-level and tail-kernel paths; off again afterwards."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    monkeypatch.setenv("HIPEXEC_TAIL_MAX", tail_max)
+    fs = scenegen.small_variant("glass").to_flat()
+    orc = Oracle(fs)
+    W, H, depth = 72, 56, 5
+    ref = orc.render(W, H, mode=CPU, max_depth=depth, tone=0, n_threads=8, refract=True)
+    plain = orc.render(W, H, mode=CPU, max_depth=depth, tone=0, n_threads=8)
+    assert not np.array_equal(ref["linear"], plain["linear"]) and ref["stats"].rays_bounce != plain["stats"].rays_bounce
+    with HipExecutor(fs, device=0) as ex:
+        for algo in ("bvh", "scan"):
+            for _ in range(2):
+                got = ex.render(W, H, mode=CPU, max_depth=depth, tone=False, refract=True, algo=algo)
+                assert np.array_equal(got["ids"], ref["ids"])
+                assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+                for k in ("rays_primary", "rays_bounce", "rays_shadow"):
+                    assert getattr(got["stats"], k) == getattr(ref["stats"], k), (algo, k)
+            back = ex.render(W, H, mode=CPU, max_depth=depth, tone=False, algo=algo)
+            assert ulp_diff(back["rgb"], plain["linear"]).max() <= 4
+            assert back["stats"].rays_bounce == plain["stats"].rays_bounce
+        toned = ex.render(W, H, mode=CPU, max_depth=depth, refract=True)
+        assert_image_parity(toned["rgb"], orc.render(W, H, mode=CPU, max_depth=depth, tone=1, n_threads=8, refract=True)["rgb"])

@@ -278,3 +278,69 @@ def test_bilinear_mode_is_the_nearest_lookup_at_texel_centres_and_blends_between
     c = [o.tex_get(0, 1, 1), o.tex_get(0, 2, 1), o.tex_get(0, 1, 2), o.tex_get(0, 2, 2)]
     want = (c[0] * 0.75 + c[1] * 0.25) * 0.25 + (c[2] * 0.75 + c[3] * 0.25) * 0.75
     assert np.allclose(q, want, rtol=0, atol=1e-6)
+
+
+# ---- optional refraction mode (HIPEXEC_FLAG_REFRACT; NOT reference behaviour: defined in include/hip_executor.h) ----
+def _pane_scene(flip, ior, target):
+    """Camera at the origin looking down -Z; a large pane through (0,0,-5) tilted 45 degrees about X, made of a material
+    with refractionFactor 0.5; one more quad (`target`: (y0, y1, z) of a wall facing the camera, or (x.., "ceiling")).
+    No lamps: every hit contributes the ambient colour, every miss the horizon colour."""
+    from raytracer_amd.scenegen import SceneSpec, material
+    s = np.float32(20.0)
+    # pane: points p + a*(1,0,0) + b*(0,1,-1): normal ~ (0, 1, 1)/sqrt2 (towards the camera) for the first winding
+    quad = np.array([[-s, -s, -5 + s], [s, -s, -5 + s], [s, s, -5 - s], [-s, s, -5 - s]], np.float32)
+    faces = [[0, 1, 2], [0, 2, 3]]
+    if flip:
+        faces = [[0, 2, 1], [0, 3, 2]]
+    verts = [quad]
+    if target[0] == "wall":
+        _, y0, y1, z = target
+        verts.append(np.array([[-3, y0, z], [3, y0, z], [3, y1, z], [-3, y1, z]], np.float32))
+    else:
+        _, y = target
+        verts.append(np.array([[-3, y, -8], [3, y, -8], [3, y, -2], [-3, y, -2]], np.float32))
+    faces += [[4, 5, 6], [4, 6, 7]]
+    mats = [material((0, 0, 0), kd=0, ks=0, hard=1, kt=0.5, ior=ior), material((0, 0, 0), kd=0, ks=0, hard=1)]
+    return SceneSpec(np.concatenate(verts), np.asarray(faces), None, None, np.array([0, 0, 1, 1], np.int32), mats, [], [],
+                     np.eye(3, dtype=np.float32), np.zeros(3, np.float32),
+                     {"ambientColor": [0.1, 0.2, 0.3], "horizonColor": [0.5, 0.6, 0.8], "ambientFactor": 0.0}).to_flat()
+
+
+def _centre(fs, refract, depth=1):
+    from oracle.binding import Oracle
+    r = Oracle(fs).render_region(64, 64, 32, 32, 1, 1, max_depth=depth, tone=0, refract=refract)
+    return r["linear"][0, 0], r["ids"][0, 0]
+
+
+def test_refraction_bends_towards_the_normal_on_entering():
+    """45 degrees onto n = 1.5: sin(t) = sin(45)/1.5, the ray leaves the straight line by 16.87 degrees: from (0,0,-5) it
+    reaches z = -15 at y = -10*tan(16.87 deg) = -3.03.  A wall covering y in [-6, -1.5] there is hit by the bent ray only."""
+    a, hz = np.float32([0.1, 0.2, 0.3]), np.float32([0.5, 0.6, 0.8])
+    bent = _pane_scene(False, 1.5, ("wall", -6.0, -1.5, -15.0))
+    lin, ids = _centre(bent, True)
+    assert np.isin(ids, (0, 1)).all()                                           # one of the pane's two triangles
+    assert np.allclose(lin, a + np.float32(0.5) * a, rtol=1e-6)                 # pane (ambient) + 0.5 * wall (ambient)
+    lin, _ = _centre(_pane_scene(False, 1.0, ("wall", -6.0, -1.5, -15.0)), True)
+    assert np.allclose(lin, a + np.float32(0.5) * hz, rtol=1e-6)                # index 1: straight on, misses the wall
+    lin, _ = _centre(bent, False)
+    assert np.allclose(lin, a, rtol=1e-6)                                       # mode off: reflectionFactor is 0, the path ends
+    lin, _ = _centre(_pane_scene(False, 0.0, ("wall", -6.0, -1.5, -15.0)), True)
+    assert np.allclose(lin, a + np.float32(0.5) * hz, rtol=1e-6)                # index <= 0 counts as 1
+    # the offset itself: a wall that ends 0.2 above / 0.2 below y = -3.03 separates hit from miss (the four sub-samples spread by 0.06)
+    y = -10.0 * np.tan(np.deg2rad(45.0) - np.arcsin(np.sin(np.deg2rad(45.0)) / 1.5))
+    assert abs(y + 3.03) < 0.01
+    lin, _ = _centre(_pane_scene(False, 1.5, ("wall", -6.0, y + 0.2, -15.0)), True)
+    assert np.allclose(lin, a + np.float32(0.5) * a, rtol=1e-6)
+    lin, _ = _centre(_pane_scene(False, 1.5, ("wall", -6.0, y - 0.2, -15.0)), True)
+    assert np.allclose(lin, a + np.float32(0.5) * hz, rtol=1e-6)
+
+
+def test_total_internal_reflection_takes_the_mirrored_ray():
+    """Leaving n = 1.5 at 45 degrees (critical angle 41.8): k = 1 - 2.25 * 0.5 < 0, the secondary ray is the mirrored one,
+    (0,0,-1) - 2N(d.N) = (0,1,0) straight up from (0,0,-5); a ceiling patch above is hit.  At n = 1.3 (critical angle
+    50.3) the ray leaves instead, bent away from the normal, and misses the patch."""
+    a, hz = np.float32([0.1, 0.2, 0.3]), np.float32([0.5, 0.6, 0.8])
+    lin, _ = _centre(_pane_scene(True, 1.5, ("ceiling", 8.0)), True)
+    assert np.allclose(lin, a + np.float32(0.5) * a, rtol=1e-6)
+    lin, _ = _centre(_pane_scene(True, 1.3, ("ceiling", 8.0)), True)
+    assert np.allclose(lin, a + np.float32(0.5) * hz, rtol=1e-6)
