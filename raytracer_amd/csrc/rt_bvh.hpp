@@ -320,8 +320,12 @@ DEV bool tri_exact_rec(f3 o, f3 d, f3 p, f3 e1, f3 e2, f3 c21, float &t, float &
     return true;
 }
 
-// winner rule of the linear scans made explicit: smaller t, then smaller triangle index
+// winner rule of the linear scans made explicit: smaller t, then smaller triangle index; the CPU tracer accepts a
+// candidate only with t > 0 (ray_tracer.cpp:214), which also keeps out a NaN t (overflowing determinants pass every
+// threshold comparison of the exact test), the OpenCL executor takes every flagged hit (opencl_executor.cpp:242)
+template <int MODE>
 DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
+    if (MODE != HIPEXEC_MODE_CL && !(t > 0)) return;
     if (b.id < 0 || t < b.t || (t == b.t && id < b.id)) { b.t = t; b.u = u; b.v = v; b.id = id; }
 }
 
@@ -446,7 +450,7 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
                 if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
                     if (ANY) found = 1u;
                     else {
-                        best_update_indexed(best, t, u, v, (int)B.ids[k]);
+                        best_update_indexed<MODE>(best, t, u, v, (int)B.ids[k]);
                         limit = fminf(limit, best.t);
                     }
                 }
@@ -471,7 +475,7 @@ DEV bool bvh_linear(const DBvh &B, f3 o, f3 d, Best &best, uint32_t &n_tris) {
         float t, u, v;
         if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
             if (ANY) found = true;
-            else best_update_indexed(best, t, u, v, (int)B.ids[k]);
+            else best_update_indexed<MODE>(best, t, u, v, (int)B.ids[k]);
         }
     }
     return found;
@@ -528,7 +532,7 @@ DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float 
                     if (tri_exact_rec<MODE>(o, d, xyz(e0), xyz(e1), xyz(e2), mk(e0.w, e1.w, e2.w), t, u, v)) {
                         if (ANY) found = 1u;
                         else {
-                            best_update_indexed(best, t, u, v, (int)B.ids[k]);
+                            best_update_indexed<MODE>(best, t, u, v, (int)B.ids[k]);
                             limit = fminf(limit, best.t);
                         }
                     }

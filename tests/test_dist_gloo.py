@@ -79,3 +79,34 @@ def test_tile_bookkeeping():
             f = rdist.deinterleave(g, H)
             assert f.shape[0] == H
             assert torch.equal(f[:, 0, 0], torch.arange(H) // 8 * 1.0)
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_collectives_on_the_gpu(tmp_path):
+    """The box has one GPU, so the N > 1 gather cannot run there; what can be checked is that the RCCL backend comes up
+    in this process layout (one process per GPU, device bound before init) and moves a rendered tile buffer through the
+    same collectives bench.py issues (all_reduce of the rank count, gather to rank 0) at world size 1."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from raytracer_amd import dist as rdist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+t = torch.ones(1, device=dev); dist.all_reduce(t); assert int(t.item()) == 1
+local = torch.arange(16 * 8 * 4, dtype=torch.float32, device=dev).reshape(16, 8, 4)
+buf = [torch.empty_like(local)]
+dist.gather(local, gather_list=buf, dst=0)
+torch.cuda.synchronize()
+assert torch.equal(buf[0], local)
+assert torch.equal(rdist.gather_frame(local, 13), local[:13])
+dist.barrier(); dist.destroy_process_group()
+print("rccl ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-1500:]

@@ -264,3 +264,45 @@ def test_random_soups_bvh_equals_scan(seed, n_tri, extent):
                 assert np.array_equal(res["bvh"][off], ref["id"])
                 assert np.array_equal(res["bvh"][off + 1], ref["t"].view(np.int32))
                 assert np.array_equal(res["bvh"][off + 4], orc.any_hits(rays, mode) != 0)
+
+
+def test_astronomic_coordinates_nan_candidates():
+    """Triangles with coordinates around 1e17 (still below the bound up to which a hierarchy is built): the four
+    determinants of the exact test overflow to inf and t = inf - inf = NaN passes every threshold comparison
+    (`t < EPS` is false for NaN, ray_tracer.cpp:315).  The CPU tracer's scan then drops the candidate because it
+    demands t > 0 (ray_tracer.cpp:214); the hierarchy must do the same, so that hierarchy, scan and oracle agree on
+    every ray, including the ones whose only candidates are such NaN hits."""
+    from raytracer_amd.executor import HipExecutor
+    from raytracer_amd.scene import FlatScene
+    from oracle.binding import Oracle
+    rng = np.random.default_rng(77)
+    n = 600
+    scale = np.float32(1.0e17)
+    c = rng.uniform(-1, 1, (n, 1, 3)) * scale
+    v = (c + rng.normal(size=(n, 3, 3)) * scale * rng.choice([1e-3, 0.1, 1.0], (n, 1, 1))).astype(np.float32)
+    fs = FlatScene()
+    fs.tri_p = v[:, 0]; fs.tri_e1 = v[:, 1] - v[:, 0]; fs.tri_e2 = v[:, 2] - v[:, 0]
+    with np.errstate(all="ignore"):
+        from raytracer_amd.scene import cross_f32, normalize_f32
+        fs.tri_norm = normalize_f32(cross_f32(fs.tri_e1, fs.tri_e2))
+    fs.tri_mat = np.full(n, -1, np.int32)
+    fs.cam_pos = np.zeros(3, np.float32)
+    fs = fs.normalised()
+    k = rng.integers(0, n, 4000)
+    w = rng.uniform(0, 1, (4000, 2)).astype(np.float32)
+    tgt = fs.tri_p[k] + w[:, :1] * 0.5 * fs.tri_e1[k] + w[:, 1:] * 0.5 * fs.tri_e2[k]
+    o = (rng.uniform(-1.5, 1.5, (4000, 3)) * scale).astype(np.float32)
+    d = ((tgt - o) * rng.choice([1e-17, 1e-3, 1.0], (4000, 1))).astype(np.float32)
+    rays = np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
+    orc = Oracle(fs)
+    with HipExecutor(fs, device=0) as ex:
+        for mode in (CPU, CL):
+            ref = orc.closest_hits(rays, mode)
+            res = {}
+            for algo in ("bvh", "scan"):
+                ex.set_algorithm(algo)
+                res[algo] = ex.closest_hits(rays, mode)
+                assert np.array_equal(res[algo]["id"], ref["id"]), (mode, algo, int((res[algo]["id"] != ref["id"]).sum()))
+                assert np.array_equal(ex.any_hits(rays, mode) != 0, orc.any_hits(rays, mode) != 0), (mode, algo)
+            assert np.array_equal(res["bvh"]["t"].view(np.int32), res["scan"]["t"].view(np.int32))
+        assert (ref["id"] >= 0).any()
