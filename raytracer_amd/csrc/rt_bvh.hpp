@@ -329,11 +329,18 @@ DEV void best_update_indexed(Best &b, float t, float u, float v, int id) {
     if (b.id < 0 || t < b.t || (t == b.t && id < b.id)) { b.t = t; b.u = u; b.v = v; b.id = id; }
 }
 
+// Type of the per-lane flags of the traversal loops (found, overflow): 0/1 words, see the note above TState.
+#ifdef RT_FLAG_BOOL
+typedef bool rt_flag_t;              // forensic build only (tools/flag_forensics.py): the form that lost updates
+#else
+typedef uint32_t rt_flag_t;
+#endif
+
 // One inner-node step of a lane: the four slot boxes of record N against the ray, the nearest hit slot
 // becomes the lane's node, the others go on its stack (farthest first).
 template <bool UNIFORM, bool SORT = true, int BS = 256>
 DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__ N, float limit, uint32_t *stk, uint32_t &node, int &sp,
-                        uint32_t &overflow)
+                        rt_flag_t &overflow)
 {
     if (UNIFORM) asm volatile("; wave-uniform record" ::: );          // keeps the two instances apart (scalar vs vector fetch)
     float4 lo[4], hi[4];
@@ -391,10 +398,14 @@ DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__
 // `node` is not BVH_NONE advance until fewer than `min_active` of them are left, so that the
 // caller can hand new rays to the idle lanes before the wave runs mostly empty.
 // ---------------------------------------------------------------------------------------
-// The per-lane flags are 0/1 words on purpose: as `bool` the compiler keeps them as lane masks in
-// scalar registers, and with the loops below (wave-uniform exits, refills, spilled scalars) that
-// form lost updates on gfx950 (ROCm 7.2 hipcc); shadow rays then missed occluders.
-struct TState { uint32_t node; int sp; float limit; uint32_t found, overflow; };
+// The per-lane flags are 0/1 words on purpose.  As `bool` the compiler keeps `found` as a lane mask in scalar
+// registers, and in an earlier shadow kernel whose lanes refilled from a block list (this burst loop inlined into a
+// refill loop) the -O3 build lost occluders: reproduced with `found` alone as bool, gone at -O1 and with word flags,
+// unchanged when SGPR spills go to memory instead of VGPR lanes.  `found` is lane-local and every cross-lane operation
+// of those loops runs with the wave converged, so the source has no undefined behaviour for an optimiser to use: a
+// code-generation defect of ROCm 7.2's hipcc for an i1 value live across nested divergent loops.  Today's kernels
+// give identical results in both forms (-DRT_FLAG_BOOL builds the other one for the regression test).
+struct TState { uint32_t node; int sp; float limit; rt_flag_t found, overflow; };
 DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris, uint32_t n_rays);
 
 // Every iteration the wave takes ONE of two steps, whichever more of its lanes are waiting for:
@@ -409,7 +420,7 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
     uint32_t node = st.node;
     int sp = st.sp;
     float limit = st.limit;
-    uint32_t found = st.found, overflow = st.overflow;
+    rt_flag_t found = st.found, overflow = st.overflow;
     for (;;) {
         const bool at_leaf = (node & BVH_LEAF) != 0u;                    // BVH_NONE has the bit clear
         const bool at_inner = !at_leaf && node != BVH_NONE;

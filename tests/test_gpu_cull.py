@@ -306,3 +306,25 @@ def test_astronomic_coordinates_nan_candidates():
                 assert np.array_equal(ex.any_hits(rays, mode) != 0, orc.any_hits(rays, mode) != 0), (mode, algo)
             assert np.array_equal(res["bvh"]["t"].view(np.int32), res["scan"]["t"].view(np.int32))
         assert (ref["id"] >= 0).any()
+
+
+@pytest.mark.parametrize("form", ["word", "bool"])
+def test_lane_flag_forms_give_the_oracles_answers(form):
+    """Regression test of the lane-flag episode: a traversal whose per-lane `found` flag was a `bool` lost occluders
+    under -O3 (119 of 9563 shadow rays of the soup scene) while the same code with 0/1 words did not.  The shipped
+    library uses words; its twin built with -DRT_FLAG_BOOL is the other form.  Both must give the oracle's any-hit and
+    closest-hit answers and frames on the soups (shadow rays, bounce rays, stack-overflow fallback included).  If a
+    kernel change ever exposes the defect again, the bool form fails here first."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "raytracer_amd", "lib", "libhip_executor.so" if form == "word" else "libhip_executor_boolflags.so")
+    if not os.path.exists(lib):
+        pytest.fail(f"{lib} is missing: run __graft_entry__.build()")
+    # a process of its own: the library under test is chosen before the binding loads anything
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "flag_forensics.py"), lib], capture_output=True, text=True,
+                       timeout=280, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "TOTAL MISMATCHES 0" in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("any-hit mismatches 0 of") == 10
