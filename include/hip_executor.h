@@ -99,6 +99,8 @@ typedef struct hipexec_scene_desc {
     const float   *mat_kt;     /* [n_mat]  refractionFactor: weight of the refracted ray's colour            */
     const float   *mat_ior;    /* [n_mat]  refractionHardness, taken as the relative index of refraction
                                            (values <= 0 count as 1)                                          */
+    float ambient_factor;      /* worldAmbientFactor (scene.h:152, scene.cpp:30); only HIPEXEC_FLAG_AO reads it, as the
+                                  reference's ENABLE_AO build does (ray_tracer.cpp:423)                     */
 } hipexec_scene_desc;
 
 /* Run-time counterpart of the compile-time knobs of config.h:8-20. */
@@ -140,6 +142,19 @@ typedef struct hipexec_render_cfg {
                                          and takes the mirrored direction d - 2N(d.N), otherwise the direction is
                                          eta*i + (eta*cos - sqrt(k))*normal.  Shadow rays are unchanged (transmissive
                                          objects still cast full shadows).  Frame entry points only.                    */
+
+#define HIPEXEC_FLAG_AO           32   /* The reference's optional ambient occlusion (ENABLE_AO, ray_tracer.cpp:167-169,406-435; off in
+                                         config.h:11) with its libc rand() replaced by a counter-based generator, so the result
+                                         is a function of the scene and not of thread schedules: after the ambient colour,
+                                         ret += hit.color * ao with ao = (sum over HIPEXEC_AO_RAYS rays i of ambient_factor if the
+                                         ray (P, r_i) is unoccluded) / HIPEXEC_AO_RAYS; r_i = (|2 u_{3i}| - 1, |2 u_{3i+1}| - 1,
+                                         |2 u_{3i+2}| - 1), negated if dot(r_i, N') < EPS, N' = N or -N facing the viewer
+                                         (ray_tracer.cpp:414,426-434); u_c = (h >> 8) * 2^-24 in [0,1) with
+                                         h = pcg(pcg(pcg(pcg(c) ^ bits(P.x)) ^ bits(P.y)) ^ bits(P.z)),
+                                         pcg(v): v = v*747796405 + 2891336453; w = ((v >> ((v >> 28) + 4)) ^ v) * 277803737;
+                                         return (w >> 22) ^ w.  HIPEXEC_MODE_CPU, hierarchy algorithm, at most 32 lamps; its
+                                         rays are counted as shadow rays.  Not reference parity (rand() cannot be reproduced). */
+#define HIPEXEC_AO_RAYS 30            /* AO_RAYS_COUNT, config.h:14 */
 
 /* Both algorithms evaluate the same exact ray/primitive arithmetic and return identical hits and
  * colours; they differ in which tests they can prove unnecessary. */

@@ -97,6 +97,7 @@ private:
         // so camMat[i][c] = transform[i][c] = cam_mat[3*i + c]
         for (int i = 0; i < 3; i++) for (int c = 0; c < 3; c++) d_.cam_mat[3 * i + c] = s.camMat[i][c];
         d_.horizon[0] = s.worldHorizonColor.x; d_.horizon[1] = s.worldHorizonColor.y; d_.horizon[2] = s.worldHorizonColor.z;
+        d_.ambient_factor = s.worldAmbientFactor;
         d_.ambient[0] = s.worldAmbientColor.x; d_.ambient[1] = s.worldAmbientColor.y; d_.ambient[2] = s.worldAmbientColor.z;
     }
 };

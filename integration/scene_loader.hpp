@@ -37,6 +37,7 @@ public:
     std::vector<float> lamp_pos, lamp_intensity, lamp_distance;
     float cam_pos[3] = {0, 0, 0}, cam_mat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     float horizon[3] = {0.3f, 0.3f, 0.3f}, ambient[3] = {0, 0, 0};
+    float ambient_factor = 0.0f;
 
     static LoadedScene from_file(const std::string &path) {
         std::vector<uint8_t> bytes = read_file(path);
@@ -52,6 +53,7 @@ public:
         if (!world.is_null()) {
             vec3(world.need("ambientColor"), s.ambient);
             vec3(world.need("horizonColor"), s.horizon);
+            if (!world.get("ambientFactor").is_null()) s.ambient_factor = world.get("ambientFactor").f32();     // scene.cpp:30
         }
         const Json &mats = doc.get("materials");
         std::vector<float> scale_x, scale_y;
@@ -163,6 +165,7 @@ public:
         d.lamp_pos = lamp_pos.data(); d.lamp_intensity = lamp_intensity.data(); d.lamp_distance = lamp_distance.data();
         for (int k = 0; k < 3; k++) { d.cam_pos[k] = cam_pos[k]; d.horizon[k] = horizon[k]; d.ambient[k] = ambient[k]; }
         for (int k = 0; k < 9; k++) d.cam_mat[k] = cam_mat[k];
+        d.ambient_factor = ambient_factor;
         return d;
     }
 

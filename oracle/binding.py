@@ -113,10 +113,10 @@ class Oracle:
         return colours
 
     def render_region(self, width, height, x, y, w, h, mode=_abi.HIPEXEC_MODE_CPU, max_depth=0, tone=1, n_threads=1,
-                      bilinear=False, refract=False):
+                      bilinear=False, refract=False, ao=False):
         """-> dict(rgb [h][w][3], linear [h][w][3], ids [h][w][spp], stats)"""
         cfg = _abi.RenderCfg(width, height, mode, max_depth, tone, 0, 1,
-                             (_abi.HIPEXEC_FLAG_BILINEAR if bilinear else 0) | (_abi.HIPEXEC_FLAG_REFRACT if refract else 0))
+                             (_abi.HIPEXEC_FLAG_BILINEAR if bilinear else 0) | (_abi.HIPEXEC_FLAG_REFRACT if refract else 0) | (_abi.HIPEXEC_FLAG_AO if ao else 0))
         spp = 1 if mode == _abi.HIPEXEC_MODE_CL else 4
         rgb = np.zeros((h, w, 3), np.float32); lin = np.zeros((h, w, 3), np.float32)
         ids = np.full((h, w, spp), -2, np.int32)

@@ -210,6 +210,7 @@ void orc_tex_bilinear(const hipexec_scene_desc *s, int tex, float ux, float uy, 
 
 static __thread int tl_bilinear = 0;      /* set per worker thread from hipexec_render_cfg.flags */
 static __thread int tl_refract = 0;       /* likewise: HIPEXEC_FLAG_REFRACT */
+static __thread int tl_ao = 0;            /* likewise: HIPEXEC_FLAG_AO */
 
 /* (unsigned int) of a float as x86-64 gcc evaluates it: truncate to a 64-bit integer, keep
  * the low 32 bits (ray_tracer.cpp:236-237).  Out-of-range and NaN give 0 like cvttss2si. */
@@ -352,6 +353,40 @@ static void count_closest(const hipexec_scene_desc *s, hipexec_stats *st, int de
     st->tests_sph_closest += s->n_sph;
 }
 
+static int any_hit(const hipexec_scene_desc *s, int mode, v3 o, v3 d, hipexec_stats *st);
+
+/* Counter-based stand-in for rand() / RAND_MAX of generateRandomRayInHalfSphere (ray_tracer.cpp:426-434): the c-th
+ * uniform value in [0, 1) for the hit point P (definition in include/hip_executor.h, HIPEXEC_FLAG_AO). */
+static uint32_t pcg(uint32_t v)
+{
+    v = v * 747796405u + 2891336453u;
+    uint32_t w = ((v >> ((v >> 28) + 4u)) ^ v) * 277803737u;
+    return (w >> 22) ^ w;
+}
+static float ao_uniform(v3 P, uint32_t c)
+{
+    uint32_t bx, by, bz;
+    memcpy(&bx, &P.x, 4); memcpy(&by, &P.y, 4); memcpy(&bz, &P.z, 4);
+    uint32_t h = pcg(pcg(pcg(pcg(c) ^ bx) ^ by) ^ bz);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+/* computeAmbientOcclusion, ray_tracer.cpp:406-424, with the generator above */
+static float ambient_occlusion(const hipexec_scene_desc *s, v3 P, v3 N, v3 d, hipexec_stats *st)
+{
+    float ret = 0.0f;
+    for (uint32_t i = 0; i < HIPEXEC_AO_RAYS; i++) {
+        v3 realNorm = dot(d, N) < 0.0f ? N : neg(N);
+        float rx = fabsf(2.0f * ao_uniform(P, 3 * i)) - 1.0f;
+        float ry = fabsf(2.0f * ao_uniform(P, 3 * i + 1)) - 1.0f;
+        float rz = fabsf(2.0f * ao_uniform(P, 3 * i + 2)) - 1.0f;
+        v3 r = V(rx, ry, rz);
+        if ((double)dot(r, realNorm) < EPS) r = neg(r);
+        if (!any_hit(s, HIPEXEC_MODE_CPU, P, r, st)) ret += s->ambient_factor;
+    }
+    return ret / (float)HIPEXEC_AO_RAYS;
+}
+
 /* traceRay, ray_tracer.cpp:156-201.  max_depth = 0 stands for a build without ENABLE_REFLECTION. */
 static v3 trace_cpu(const hipexec_scene_desc *s, v3 o, v3 d, int depth, int max_depth,
                     hipexec_stats *st, int *id_out)
@@ -362,6 +397,7 @@ static v3 trace_cpu(const hipexec_scene_desc *s, v3 o, v3 d, int depth, int max_
     if (!hit.isHit) return ld3(s->horizon);
     mat_t m = get_mat(s, hit.mat);
     v3 ret = ld3(s->ambient);
+    if (tl_ao) ret = add(ret, muls(hit.color, ambient_occlusion(s, hit.point, hit.norm, d, st)));      /* ray_tracer.cpp:167-169 */
     for (uint32_t l = 0; l < s->n_lamp; l++) {
         int shaded = 0;
         v3 toLamp = sub(ld3(s->lamp_pos + 3 * l), hit.point);
@@ -470,6 +506,7 @@ static void render_block(const job_t *J, int bx, int by, int bw, int bh, hipexec
     int cl = (J->cfg->mode == HIPEXEC_MODE_CL);
     tl_bilinear = (J->cfg->flags & HIPEXEC_FLAG_BILINEAR) != 0;
     tl_refract = (J->cfg->flags & HIPEXEC_FLAG_REFRACT) != 0;
+    tl_ao = (J->cfg->flags & HIPEXEC_FLAG_AO) != 0;
     int spp = cl ? 1 : 4;
     float camHeight = 0.5;
     float camWidth = (float)width * (camHeight / (float)height);

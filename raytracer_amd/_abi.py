@@ -16,6 +16,7 @@ HIPEXEC_FLAG_SCAN = 2
 HIPEXEC_FLAG_BVH = 4
 HIPEXEC_FLAG_BILINEAR = 8
 HIPEXEC_FLAG_REFRACT = 16
+HIPEXEC_FLAG_AO = 32
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
 ABI_VERSION = 4
@@ -37,7 +38,7 @@ class SceneDesc(C.Structure):
         ("n_lamp", C.c_uint32), ("lamp_pos", _fp), ("lamp_intensity", _fp), ("lamp_distance", _fp),
         ("cam_pos", C.c_float * 3), ("cam_mat", C.c_float * 9),
         ("horizon", C.c_float * 3), ("ambient", C.c_float * 3),
-        ("mat_kt", _fp), ("mat_ior", _fp),
+        ("mat_kt", _fp), ("mat_ior", _fp), ("ambient_factor", C.c_float),
     ]
 
 

@@ -379,6 +379,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     h->lamp_words = std::max(1u, (s->n_lamp + 31u) / 32u);
     memcpy(S.cam_pos, s->cam_pos, sizeof S.cam_pos); memcpy(S.cam_mat, s->cam_mat, sizeof S.cam_mat);
     memcpy(S.horizon, s->horizon, sizeof S.horizon); memcpy(S.ambient, s->ambient, sizeof S.ambient);
+    S.ambient_factor = s->ambient_factor;
 
     // centre of the scene's bounding box: origin of the FILTER coordinates
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -557,6 +558,9 @@ int call_begin(hipexec *h, uint32_t timing, uint32_t flags)
     h->use_bvh = want_bvh && h->bvh_ok;
     h->S.bilinear = (flags & HIPEXEC_FLAG_BILINEAR) ? 1u : 0u;
     h->S.refract = (flags & HIPEXEC_FLAG_REFRACT) ? 1u : 0u;
+    h->S.ao = (flags & HIPEXEC_FLAG_AO) ? 1u : 0u;
+    if (h->S.ao && (!h->use_bvh || h->lamp_words != 1))
+        return fail(HIPEXEC_E_LIMIT, "HIPEXEC_FLAG_AO needs the hierarchy algorithm and at most 32 lamps");
     if (h->call_open) {   // a previous asynchronous call has not been collected yet (or failed half-way)
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->side) HIPCHK(hipStreamSynchronize(h->side));
@@ -808,6 +812,7 @@ constexpr uint32_t OVERLAP_MAX_SAMPLES = 2500000u;
 // (1/8 of C2 +5 %), so those keep the two launches.
 bool fused_shading(const hipexec *h, bool side_stream)
 {
+    if (h->S.ao) return true;                 // the occlusion sum of a sample stays in the registers of the kernel that traced it
     if (h->lamp_words != 1 || h->fuse_shade == 0) return false;
     return h->fuse_shade == 2 || (!side_stream && h->S.n_lamp <= 8);
 }
@@ -816,7 +821,7 @@ bool fused_shading(const hipexec *h, bool side_stream)
 // level alone the separate, coherent kernels are as good).
 bool use_tail(const hipexec *h, uint32_t n_rays, int level, int depth)
 {
-    return h->use_bvh && h->bvh_refill && n_rays <= h->tail_max && level < depth;
+    return h->use_bvh && h->bvh_refill && n_rays <= h->tail_max && level < depth && !h->S.ao;
 }
 
 template <int MODE>
@@ -842,10 +847,11 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
     const uint32_t per_block = small_launch_share(n, h->shadow_per_block);
     const uint32_t blocks = (n + per_block - 1) / per_block;
     const float4 *nodes_sc = h->uniform_fetch ? h->B.nodes : nullptr;
-    if (h->shadow_direct && (h->block_shadow == 64 || n <= h->block64_below))
+    const bool direct = h->shadow_direct || h->S.ao;       // the occlusion rays of HIPEXEC_FLAG_AO exist in the direct form only
+    if (direct && (h->block_shadow == 64 || n <= h->block64_below))
         LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
-    else if (h->shadow_direct)
+    else if (direct)
         LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
                   h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     else
@@ -1077,7 +1083,7 @@ int render_tiles(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int32_
         int levels_used = 1;
         const std::array<int64_t, 24> key = {1, c->width, c->height, MODE, depth, c->tile_first, c->tile_step, h->win_lo, h->win_hi,
                                              cx0, cy0, cx1, cy1, sub, n_sub, t0, (int64_t)n0, h->use_bvh, h->tail_max, h->overlap_levels,
-                                             h->bvh_refill, h->fuse_shade, (int64_t)h->simple_from, (int64_t)h->S.refract};
+                                             h->bvh_refill, h->fuse_shade, (int64_t)h->simple_from, (int64_t)(h->S.refract | (h->S.ao << 1))};
         CHK(trace_levels<MODE>(h, (uint32_t)n0, (size_t)n0, depth, &levels_used, key));
         LAUNCH(HIPEXEC_K_SHADE, (k_resolve<MODE>), blocks_for(F.n_slots), F, h->local.as<float4>(), (size_t)n0, levels_used,
                h->hit0.as<float4>(), c->tone, d_rgba, d_ids);
@@ -1141,7 +1147,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
             rcs[(size_t)k] = [&]() -> int {
                 HIPCHK(hipSetDevice(g->device));
                 HIPCHK(hipStreamWaitEvent(g->stream, h->ev_fork, 0));
-                CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & (HIPEXEC_FLAG_BILINEAR | HIPEXEC_FLAG_REFRACT))));
+                CHK(call_begin(g, h->timing, HIPEXEC_FLAG_BVH | ((uint32_t)c->flags & (HIPEXEC_FLAG_BILINEAR | HIPEXEC_FLAG_REFRACT | HIPEXEC_FLAG_AO))));
                 return render_sub(g, c, d_rgba, d_ids, k, L);
             }();
             if (rcs[(size_t)k] != HIPEXEC_OK) errs[(size_t)k] = g_err;          // g_err is per thread

@@ -1059,6 +1059,28 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_
             n_rays++;
         }
     }
+    // HIPEXEC_FLAG_AO: the occlusion rays of computeAmbientOcclusion (ray_tracer.cpp:406-424), one after the other like the
+    // lamp rays; the sum is formed in the reference's order
+    float ao = 0.0f;
+    if (FUSED && MODE == HIPEXEC_MODE_CPU && S.ao) {
+        const f3 realNorm = dotWithDir < 0.0f ? sf.N : -sf.N;
+        for (uint32_t i = 0; i < (uint32_t)HIPEXEC_AO_RAYS; i++) {
+            if (hit) {
+                const f3 rd = ao_ray(P, realNorm, i);
+                bool occluded = false;
+                for (uint32_t k = 0; k < n_sl && !occluded; k++) { float4 sp = sph_lds[k]; float t; occluded = sph_exact<MODE>(P, rd, xyz(sp), sp.w, t); }
+                for (uint32_t k = n_sl; k < S.n_sph && !occluded; k++) { float4 sp = S.sph[k]; float t; occluded = sph_exact<MODE>(P, rd, xyz(sp), sp.w, t); }
+                if (!occluded) {
+                    TRay r = tray_make(S, B, P, rd);
+                    Best none = best_none();
+                    occluded = bvh_traverse<MODE, true, BS>(B, r, P, rd, __builtin_inff(), none, &stack[0][tid], n_nodes, n_tris, nodes_sc);
+                }
+                if (!occluded) ao += S.ambient_factor;
+                n_rays++;
+            }
+        }
+        ao = ao / (float)HIPEXEC_AO_RAYS;
+    }
     if (FUSED) {
         bool bounce = false;
         f3 bo = mk(0.f, 0.f, 0.f), bd = mk(0.f, 0.f, 1.f);
@@ -1066,7 +1088,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_
             load_ray(rays, j, o, d, s, aux);
             float4 hh = hits[j];
             if (__float_as_int(hh.w) >= -1)
-                local[s] = shade_sample<MODE>(S, o, d, hh, &occ_bits, spawn != 0, bounce, bo, bd);
+                local[s] = shade_sample<MODE>(S, o, d, hh, &occ_bits, spawn != 0, bounce, bo, bd, ao);
         }
         if (spawn && next_rays) {
             __shared__ uint32_t append_scratch[5];

@@ -86,6 +86,8 @@ struct DScene {
     uint32_t cull;           // 1: skip chunks no ray of the wave can hit; 0: scan every chunk
     uint32_t bilinear;       // 1: HIPEXEC_FLAG_BILINEAR for this call (not a reference mode)
     uint32_t refract;        // 1: HIPEXEC_FLAG_REFRACT for this call (not a reference mode)
+    uint32_t ao;             // 1: HIPEXEC_FLAG_AO for this call (the reference's ENABLE_AO with a counter-based generator)
+    float ambient_factor;    // worldAmbientFactor
     const float2 *mat_c;     // {refractionFactor, refractionHardness = index of refraction}   [n_mat + 1]
     const float *tri_norm;   // [n][3]
     const float *tri_uv;     // [n][6]
@@ -394,6 +396,25 @@ DEV bool secondary_ray(const DScene &S, int mat, float kr, f3 d, f3 N, float &w,
         return true;
     }
     return false;
+}
+
+// HIPEXEC_FLAG_AO: the c-th uniform value in [0, 1) for hit point P, and the i-th occlusion ray of
+// generateRandomRayInHalfSphere (ray_tracer.cpp:426-434) built from three of them (definition in hip_executor.h)
+DEV uint32_t pcg_hash(uint32_t v) {
+    v = v * 747796405u + 2891336453u;
+    uint32_t w = ((v >> ((v >> 28) + 4u)) ^ v) * 277803737u;
+    return (w >> 22) ^ w;
+}
+DEV float ao_uniform(f3 P, uint32_t c) {
+    uint32_t h = pcg_hash(pcg_hash(pcg_hash(pcg_hash(c) ^ __float_as_uint(P.x)) ^ __float_as_uint(P.y)) ^ __float_as_uint(P.z));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+DEV f3 ao_ray(f3 P, f3 realNorm, uint32_t i) {
+    float rx = fabsf(2.0f * ao_uniform(P, 3u * i)) - 1.0f;
+    float ry = fabsf(2.0f * ao_uniform(P, 3u * i + 1u)) - 1.0f;
+    float rz = fabsf(2.0f * ao_uniform(P, 3u * i + 2u)) - 1.0f;
+    f3 r = mk(rx, ry, rz);
+    return (dot(r, realNorm) <= RT_EPSF) ? -r : r;          // `< EPS` in double
 }
 
 // powf(x, y) of the shading code.  Evaluated in double and rounded once: correctly rounded

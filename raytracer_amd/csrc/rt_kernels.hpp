@@ -883,7 +883,8 @@ __global__ __launch_bounds__(256) void k_shadowgen(DScene S, const float4 *__res
 // ray_tracer_cl.cpp:119-174).  `occ` points at the sample's occlusion words (bit l: lamp l is hidden).
 // ---------------------------------------------------------------------------------------
 template <int MODE>
-DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *occ, bool spawn, bool &bounce, f3 &bo, f3 &bd)
+DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *occ, bool spawn, bool &bounce, f3 &bo, f3 &bd,
+                        float ao = 0.0f)
 {
     f3 ret; float w = -1.0f;
     if (__float_as_int(h.w) < 0) {
@@ -893,6 +894,7 @@ DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *o
     } else {
         Surf sf = surface(S, o, d, h, true);
         ret = (MODE == HIPEXEC_MODE_CL) ? mk(0.f, 0.f, 0.f) : mk(S.ambient[0], S.ambient[1], S.ambient[2]);
+        if (MODE == HIPEXEC_MODE_CPU && S.ao) ret = ret + sf.color * ao;           // ray_tracer.cpp:167-169
         for (uint32_t l = 0; l < S.n_lamp; l++) {
             float4 lp = S.lamp[l];
             f3 toLamp = xyz(lp) - sf.P;

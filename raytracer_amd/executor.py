@@ -72,7 +72,7 @@ class HipExecutor:
 
     # -- frame ----------------------------------------------------------------------------
     @staticmethod
-    def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo=None, bilinear=False, refract=False):
+    def _cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo=None, bilinear=False, refract=False, ao=False):
         # time_kernels: False / True (every kernel class) / an iterable of class indices (only those classes)
         flags = 0
         if time_kernels is True:
@@ -85,6 +85,8 @@ class HipExecutor:
             flags |= _abi.HIPEXEC_FLAG_BILINEAR
         if refract:
             flags |= _abi.HIPEXEC_FLAG_REFRACT
+        if ao:
+            flags |= _abi.HIPEXEC_FLAG_AO
         if algo is not None:
             flags |= {"scan": _abi.HIPEXEC_FLAG_SCAN, "bvh": _abi.HIPEXEC_FLAG_BVH}[algo]
         return _abi.RenderCfg(int(width), int(height), int(mode), int(max_depth), int(bool(tone)), int(tile_first),
@@ -96,14 +98,14 @@ class HipExecutor:
             self._h, {"scan": _abi.HIPEXEC_ALGO_SCAN, "bvh": _abi.HIPEXEC_ALGO_BVH}[algo]))
 
     def render(self, width, height, mode=HIPEXEC_MODE_CPU, max_depth=0, tone=True, tile_first=0, tile_step=1,
-               want_ids=True, time_kernels=False, out=None, algo=None, bilinear=False, refract=False):
+               want_ids=True, time_kernels=False, out=None, algo=None, bilinear=False, refract=False, ao=False):
         """Render to host memory.  -> dict(rgb [H][W][3] float32, ids [H][W][spp] int32 | None, stats)."""
         spp = 1 if mode == HIPEXEC_MODE_CL else 4
         rgb = out if out is not None else np.zeros((height, width, 3), np.float32)
         assert rgb.dtype == np.float32 and rgb.flags.c_contiguous and rgb.shape == (height, width, 3)
         ids = np.full((height, width, spp), -3, np.int32) if want_ids else None
         st = _abi.Stats()
-        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo, bilinear, refract)
+        cfg = self._cfg(width, height, mode, max_depth, tone, tile_first, tile_step, time_kernels, algo, bilinear, refract, ao)
         self._check(self._lib.hipexec_render(self._h, C.byref(cfg), rgb.ctypes.data,
                                              ids.ctypes.data if ids is not None else None, C.byref(st)))
         return {"rgb": rgb, "ids": ids, "stats": st}

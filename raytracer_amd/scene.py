@@ -79,6 +79,7 @@ class FlatScene:
     cam_mat: np.ndarray = field(default_factory=lambda: np.eye(3, dtype=np.float32))   # JSON transform rows
     horizon: np.ndarray = field(default_factory=lambda: np.full((3,), 0.3, np.float32))
     ambient: np.ndarray = field(default_factory=lambda: np.zeros((3,), np.float32))
+    ambient_factor: float = 0.0                # worldAmbientFactor (scene.cpp:30): only the optional AO mode reads it
 
     # ------------------------------------------------------------------------------------
     @property
@@ -167,6 +168,7 @@ class FlatScene:
         d.cam_mat[:] = [float(x) for x in self.cam_mat.reshape(-1)]
         d.horizon[:] = [float(x) for x in self.horizon]
         d.ambient[:] = [float(x) for x in self.ambient]
+        d.ambient_factor = float(np.float32(self.ambient_factor))
         return d, keep
 
 
@@ -220,6 +222,7 @@ def scene_from_json(doc: dict, base_dir: str = ".", texture_loader=decode_png_rg
     if world is not None:                                           # scene.cpp:24-35
         s.ambient = _f32(world["ambientColor"])
         s.horizon = _f32(world["horizonColor"])
+        s.ambient_factor = float(np.float32(world.get("ambientFactor", 0.0)))
     else:
         s.ambient = _f32([0.0, 0.0, 0.0]); s.horizon = _f32([0.3, 0.3, 0.3])
 

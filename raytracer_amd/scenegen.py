@@ -37,6 +37,7 @@ class SceneSpec:
         s = FlatScene()
         if self.world is not None:
             s.ambient = _f32(self.world["ambientColor"]); s.horizon = _f32(self.world["horizonColor"])
+            s.ambient_factor = float(np.float32(self.world.get("ambientFactor", 0.0)))
         else:
             s.ambient = _f32([0, 0, 0]); s.horizon = _f32([0.3, 0.3, 0.3])
         scale = []

@@ -485,3 +485,34 @@ def test_refraction_mode_matches_its_cpu_definition(monkeypatch, tail_max):
             assert back["stats"].rays_bounce == plain["stats"].rays_bounce
         toned = ex.render(W, H, mode=CPU, max_depth=depth, refract=True)
         assert_image_parity(toned["rgb"], orc.render(W, H, mode=CPU, max_depth=depth, tone=1, n_threads=8, refract=True)["rgb"])
+
+
+@pytest.mark.parametrize("name,depth", [("c1", 0), ("mirror", 2), ("c5", 0)])
+def test_ambient_occlusion_mode_matches_its_cpu_definition(name, depth):
+    """The reference's optional ambient occlusion (ENABLE_AO, ray_tracer.cpp:167-169,406-435) with its rand() replaced by a
+    counter-based generator keyed on the hit point: 30 occlusion rays per hit, all levels, against the oracle's
+    definition (ids exact, colours within 4 ULP, the occlusion rays counted as shadow rays); off again afterwards; the
+    index-order scans refuse the mode."""
+    from raytracer_amd.executor import HipExecutor, HipExecutorError
+    from oracle.binding import Oracle
+    fs = scenegen.small_variant(name).to_flat()
+    fs.ambient_factor = 0.6
+    orc = Oracle(fs)
+    W, H = 56, 40
+    ref = orc.render(W, H, mode=CPU, max_depth=depth, tone=0, n_threads=8, ao=True)
+    plain = orc.render(W, H, mode=CPU, max_depth=depth, tone=0, n_threads=8)
+    assert not np.array_equal(ref["linear"], plain["linear"])
+    assert ref["stats"].rays_shadow >= plain["stats"].rays_shadow + 30 * int((ref["ids"] >= 0).sum())
+    with HipExecutor(fs, device=0) as ex:
+        for _ in range(2):
+            got = ex.render(W, H, mode=CPU, max_depth=depth, tone=False, ao=True)
+            assert np.array_equal(got["ids"], ref["ids"])
+            assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
+            for k in ("rays_primary", "rays_bounce", "rays_shadow"):
+                assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
+        back = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
+        assert ulp_diff(back["rgb"], plain["linear"]).max() <= 4 and back["stats"].rays_shadow == plain["stats"].rays_shadow
+        with pytest.raises(HipExecutorError, match="hierarchy"):
+            ex.render(W, H, mode=CPU, max_depth=depth, ao=True, algo="scan")
+        again = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)         # the refused call leaves the executor usable
+        assert np.array_equal(again["rgb"].view(np.int32), back["rgb"].view(np.int32))

@@ -344,3 +344,36 @@ def test_total_internal_reflection_takes_the_mirrored_ray():
     assert np.allclose(lin, a + np.float32(0.5) * a, rtol=1e-6)
     lin, _ = _centre(_pane_scene(True, 1.3, ("ceiling", 8.0)), True)
     assert np.allclose(lin, a + np.float32(0.5) * hz, rtol=1e-6)
+
+
+# ---- optional ambient occlusion (HIPEXEC_FLAG_AO: ENABLE_AO of ray_tracer.cpp:167-169,406-435 with a counter-based generator) ----
+def _ao_scene(closed):
+    from raytracer_amd.scenegen import SceneSpec, material, box_mesh
+    if closed:
+        v, f = box_mesh((-3, -3, -12), (3, 3, 2))
+        f = f[:, ::-1].copy()                       # a closed room around the camera: every occlusion ray hits a wall
+    else:
+        v = np.array([[-50, -2, 50], [50, -2, 50], [50, -2, -50], [-50, -2, -50]], np.float32)      # a floor below the camera
+        f = np.array([[0, 1, 2], [0, 2, 3]], np.int64)
+    mats = [material((0.5, 0.25, 1.0), kd=0, ks=0, hard=1)]
+    from raytracer_amd.scenegen import camera
+    T, pos = camera((0, 0, 0), pitch_deg=-30)
+    return SceneSpec(v, f, None, None, np.zeros(f.shape[0], np.int32), mats, [], [], T, pos,
+                     {"ambientColor": [0.1, 0.2, 0.3], "horizonColor": [0.5, 0.6, 0.8], "ambientFactor": 0.75}).to_flat()
+
+
+def test_ambient_occlusion_open_floor_and_closed_room():
+    """No lamps.  Above an open floor every occlusion ray is turned into the hemisphere of the normal that faces the viewer
+    and escapes: ao = 30 * ambientFactor / 30, the pixel is ambient + colour * ambientFactor.  Inside a closed room every
+    occlusion ray is blocked: ao = 0, the pixel is the ambient colour.  Without the flag: ambient in both."""
+    from oracle.binding import Oracle
+    a, col, f = np.float32([0.1, 0.2, 0.3]), np.float32([0.5, 0.25, 1.0]), np.float32(0.75)
+    for closed, want in ((False, a + col * f), (True, a)):
+        fs = _ao_scene(closed)
+        assert abs(fs.ambient_factor - 0.75) < 1e-7
+        r = Oracle(fs).render_region(32, 32, 16, 4, 1, 1, max_depth=0, tone=0, ao=True)
+        assert (r["ids"] >= 0).all()
+        assert np.allclose(r["linear"][0, 0], want, rtol=2e-6), (closed, r["linear"][0, 0])
+        assert r["stats"].rays_shadow == 4 * 30                       # 30 occlusion rays per sub-sample, counted as shadow rays
+        off = Oracle(fs).render_region(32, 32, 16, 4, 1, 1, max_depth=0, tone=0)
+        assert np.allclose(off["linear"][0, 0], a, rtol=1e-6) and off["stats"].rays_shadow == 0
