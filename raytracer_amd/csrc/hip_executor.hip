@@ -174,6 +174,9 @@ struct hipexec {
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;         // chunks of the scene arena
     char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    float *d_tri_p = nullptr, *d_tri_e1 = nullptr, *d_tri_e2 = nullptr;   // the caller's triangle arrays on the device (set-up kernels read them)
+    std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
+    bool scan_ready = false;                  // the scan algorithm's records exist (ensure_scan_records)
     Buf rayA, rayB, hit0, hitN, hitM, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
     uint32_t *d_cnt32 = nullptr;              // [0] next-level queue fill, [1 + l] shadow queue fill of lamp l
     uint32_t n_cnt32 = 0;
@@ -415,38 +418,19 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     CHK(upload(h, s->tri_p, 3 * (size_t)s->n_tri, &d_p));
     CHK(upload(h, s->tri_e1, 3 * (size_t)s->n_tri, &d_e1));
     CHK(upload(h, s->tri_e2, 3 * (size_t)s->n_tri, &d_e2));
-    float4 *ex = nullptr, *px = nullptr; PairCam *pc = nullptr; PairGen *pg = nullptr;
+    h->d_tri_p = d_p; h->d_tri_e1 = d_e1; h->d_tri_e2 = d_e2;
+    float4 *ex = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &ex, 3 * (size_t)S.n_tri_pad + 1));
-    CHK(upload<float4>(h, nullptr, 0, &px, 3 * (size_t)S.n_tri_pad + 1));
-    CHK(upload<PairCam>(h, nullptr, 0, &pc, (size_t)S.n_tri_pad / 2 + 1));
-    CHK(upload<PairGen>(h, nullptr, 0, &pg, (size_t)S.n_tri_pad / 2 + 1));
     if (S.n_tri_pad) {
-        f3 cam = {S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]}, cen = {S.center[0], S.center[1], S.center[2]};
-        hipLaunchKernelGGL(k_setup_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
-                           S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, cam, cen, S.rmax, ex, px, pc, pg);
+        hipLaunchKernelGGL(k_setup_exact, dim3((S.n_tri_pad + 255) / 256), dim3(256), 0, h->stream, S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, ex);
         HIPCHK(hipGetLastError());
     }
-    S.tri_exact = ex; S.tri_primx = px; S.pair_cam = pc; S.pair_gen = pg;
-    PairCam *pl = nullptr;
-    CHK(upload<PairCam>(h, nullptr, 0, &pl, (size_t)s->n_lamp * (S.n_tri_pad / 2) + 1));
-    if (S.n_tri_pad) {
-        float abs_bound = S.rmax + std::sqrt(S.center[0] * S.center[0] + S.center[1] * S.center[1] + S.center[2] * S.center[2]);
-        for (uint32_t l = 0; l < s->n_lamp; l++) {
-            f3 L = {s->lamp_pos[3 * l], s->lamp_pos[3 * l + 1], s->lamp_pos[3 * l + 2]};
-            hipLaunchKernelGGL(k_setup_lamp_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
-                               S.n_tri, S.n_tri_pad, d_p, d_e1, d_e2, L, abs_bound, pl + (size_t)l * (S.n_tri_pad / 2));
-            HIPCHK(hipGetLastError());
-        }
-    }
-    S.pair_lamp = pl;
-    float4 *cb = nullptr;
-    uint32_t n_chunks = S.n_tri_pad / CHUNK_TRIS;
-    CHK(upload<float4>(h, nullptr, 0, &cb, 3 * (size_t)n_chunks + 1));
-    if (n_chunks) {
-        hipLaunchKernelGGL(k_setup_chunks, dim3((n_chunks + 63) / 64), dim3(64), 0, h->stream, S.n_tri, n_chunks, d_p, d_e1, d_e2, cb);
-        HIPCHK(hipGetLastError());
-    }
-    S.chunk_box = cb;
+    S.tri_exact = ex;
+    // The records of the index-order scans (filter pairs per camera / arbitrary ray / lamp, chunk boxes) are made by
+    // the first call that scans, see ensure_scan_records: the default algorithm never reads them, and an executor that
+    // is created per frame (ray_tracer_cl.cpp:14) should not pay for them.
+    S.tri_primx = nullptr; S.pair_cam = nullptr; S.pair_gen = nullptr; S.pair_lamp = nullptr; S.chunk_box = nullptr;
+    h->lamp_pos_host.assign(s->lamp_pos, s->lamp_pos + 3 * (size_t)s->n_lamp);
     {
         const char *nc = getenv("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
@@ -551,11 +535,52 @@ inline uint32_t timing_mask(int32_t flags)
 
 inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
+// Records of the index-order scan algorithm, made once, by the first call that needs them.
+int ensure_scan_records(hipexec *h)
+{
+    if (h->scan_ready) return HIPEXEC_OK;
+    DScene &S = h->S;
+    float4 *px = nullptr; PairCam *pc = nullptr; PairGen *pg = nullptr;
+    float4 *ex = const_cast<float4 *>(S.tri_exact);
+    CHK(upload<float4>(h, nullptr, 0, &px, 3 * (size_t)S.n_tri_pad + 1));
+    CHK(upload<PairCam>(h, nullptr, 0, &pc, (size_t)S.n_tri_pad / 2 + 1));
+    CHK(upload<PairGen>(h, nullptr, 0, &pg, (size_t)S.n_tri_pad / 2 + 1));
+    if (S.n_tri_pad) {
+        f3 cam = {S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]}, cen = {S.center[0], S.center[1], S.center[2]};
+        hipLaunchKernelGGL(k_setup_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                           S.n_tri, S.n_tri_pad, h->d_tri_p, h->d_tri_e1, h->d_tri_e2, cam, cen, S.rmax, ex, px, pc, pg);   // rewrites the exact records with the same bits
+        HIPCHK(hipGetLastError());
+    }
+    PairCam *pl = nullptr;
+    CHK(upload<PairCam>(h, nullptr, 0, &pl, (size_t)S.n_lamp * (S.n_tri_pad / 2) + 1));
+    if (S.n_tri_pad) {
+        float abs_bound = S.rmax + std::sqrt(S.center[0] * S.center[0] + S.center[1] * S.center[1] + S.center[2] * S.center[2]);
+        for (uint32_t l = 0; l < S.n_lamp; l++) {
+            f3 L = {h->lamp_pos_host[3 * l], h->lamp_pos_host[3 * l + 1], h->lamp_pos_host[3 * l + 2]};
+            hipLaunchKernelGGL(k_setup_lamp_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                               S.n_tri, S.n_tri_pad, h->d_tri_p, h->d_tri_e1, h->d_tri_e2, L, abs_bound, pl + (size_t)l * (S.n_tri_pad / 2));
+            HIPCHK(hipGetLastError());
+        }
+    }
+    float4 *cb = nullptr;
+    uint32_t n_chunks = S.n_tri_pad / CHUNK_TRIS;
+    CHK(upload<float4>(h, nullptr, 0, &cb, 3 * (size_t)n_chunks + 1));
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_setup_chunks, dim3((n_chunks + 63) / 64), dim3(64), 0, h->stream, S.n_tri, n_chunks, h->d_tri_p, h->d_tri_e1, h->d_tri_e2, cb);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    S.tri_primx = px; S.pair_cam = pc; S.pair_gen = pg; S.pair_lamp = pl; S.chunk_box = cb;
+    h->scan_ready = true;
+    return HIPEXEC_OK;
+}
+
 int call_begin(hipexec *h, uint32_t timing, uint32_t flags)
 {
     HIPCHK(hipSetDevice(h->device));
     bool want_bvh = (flags & HIPEXEC_FLAG_SCAN) ? false : ((flags & HIPEXEC_FLAG_BVH) ? true : h->bvh_default);
     h->use_bvh = want_bvh && h->bvh_ok;
+    if (!h->use_bvh) CHK(ensure_scan_records(h));
     h->S.bilinear = (flags & HIPEXEC_FLAG_BILINEAR) ? 1u : 0u;
     h->S.refract = (flags & HIPEXEC_FLAG_REFRACT) ? 1u : 0u;
     h->S.ao = (flags & HIPEXEC_FLAG_AO) ? 1u : 0u;
@@ -1301,6 +1326,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
         if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
         CHK(build_scene(h, scene));
+        if (!h->bvh_default || !h->bvh_ok) CHK(ensure_scan_records(h));       // the scans are this executor's algorithm
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each
         // wave reads only the chunks it needs and the scalar path wins
         if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
@@ -1367,6 +1393,10 @@ int hipexec_set_algorithm(hipexec_t *h, int algorithm)
     if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
     if (algorithm != HIPEXEC_ALGO_SCAN && algorithm != HIPEXEC_ALGO_BVH) return fail(HIPEXEC_E_INVALID, "unknown algorithm %d", algorithm);
     h->bvh_default = algorithm == HIPEXEC_ALGO_BVH;
+    if (!h->bvh_default) {                    // a set-up call may allocate; hipexec_any_hits_static later may not
+        HIPCHK(hipSetDevice(h->device));
+        CHK(ensure_scan_records(h));
+    }
     return HIPEXEC_OK;
 }
 
@@ -1609,6 +1639,9 @@ int hipexec_any_hits_static(hipexec_t *h, int mode, const float *d_rays6, uint32
     hipLaunchKernelGGL(k_import_rays, grid, blk, 0, st, d_rays6, n, recs);
     HIPCHK(hipGetLastError());
     const bool bvh = h->bvh_default && h->bvh_ok;
+    if (!bvh && !h->scan_ready)
+        return fail(HIPEXEC_E_INVALID, "the scan algorithm's records do not exist yet and this call cannot allocate them: run any other "
+                                       "call of this executor with the scan algorithm first");
     if (bvh) {
         if (mode == HIPEXEC_MODE_CL) hipLaunchKernelGGL((k_bvh_anyhit<HIPEXEC_MODE_CL>), grid, blk, 0, st, h->S, h->B, recs, n, bits, 1u, cnt);
         else hipLaunchKernelGGL((k_bvh_anyhit<HIPEXEC_MODE_CPU>), grid, blk, 0, st, h->S, h->B, recs, n, bits, 1u, cnt);

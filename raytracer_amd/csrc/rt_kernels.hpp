@@ -70,6 +70,22 @@ DEV void set_cam_half(PairCam &pc, int h, f3 cu, f3 cv, f3 cw) {
     set_half(pc.pad, h, 0.f);
 }
 
+// EXACT records alone (what the hierarchy build and both algorithms' exact tests read): one thread per triangle slot.
+__global__ void k_setup_exact(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2, float4 *tri_exact)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    if (i < n_tri) {
+        f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
+        f3 e1 = mk(te1[3 * i], te1[3 * i + 1], te1[3 * i + 2]);
+        f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
+        f3 c21 = cross(e2, e1);                      // the same operations as in k_setup_pairs
+        r0 = make_float4(p.x, p.y, p.z, c21.x); r1 = make_float4(e1.x, e1.y, e1.z, c21.y); r2 = make_float4(e2.x, e2.y, e2.z, c21.z);
+    }
+    tri_exact[3 * (size_t)i] = r0; tri_exact[3 * (size_t)i + 1] = r1; tri_exact[3 * (size_t)i + 2] = r2;
+}
+
 // One thread per pair of triangles (2j, 2j+1).  `rmax` bounds the distance of ray origins
 // from `center` the general FILTER slack is valid for (farther origins scale their threshold).
 __global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,

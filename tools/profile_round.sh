@@ -15,3 +15,8 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-brute --algo $ALGO > "$OUT/pmc_write.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_l2" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-brute --algo $ALGO > "$OUT/pmc_l2.log" 2>&1 || echo "l2 pass failed"
 echo profile_done
+# the default command as the driver runs it (throughput mode, brute-force leg and CPU baseline included): kernel trace + stats
+if [ "$ALGO" = "bvh" ]; then
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python bench.py > "$OUT/trace_default.log" 2>&1
+fi
+echo profile_done
