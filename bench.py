@@ -100,9 +100,13 @@ def pmc_quote(kernel_class, workload, algo):
             continue
         c = m.get("counters", {})
         q = {"source": os.path.relpath(files[-1], ROOT), "kernel": name}
-        for k in ("valu_utilisation", "l2_hit_rate", "occupancy_waves_per_simd"):
+        for k in ("l2_hit_rate", "occupancy_waves_per_simd"):
             if k in m:
                 q[k] = m[k]
+        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_INSTS_VALU"):
+            # fraction of the VALU issue peak: a SIMD (32 lanes wide) issues one wave64 instruction per 2 cycles;
+            # GRBM_GUI_ACTIVE is the sum over the 8 XCDs, 1024 SIMDs on the chip
+            q["valu_issue_fraction"] = c["SQ_INSTS_VALU"] * 2.0 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         if c.get("SQ_ACTIVE_INST_VALU"):
             q["live_lane_fraction"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
         if c.get("SQ_WAVE_CYCLES"):
@@ -113,15 +117,21 @@ def pmc_quote(kernel_class, workload, algo):
     return None
 
 
-def limiter_of(q):
-    """What the counters say holds the kernel back (the roofline's unit stays FLOP/s against the VALU peak)."""
-    if not q or "valu_utilisation" not in q:
+def limiter_of(q, packed_frac=0.0):
+    """What the counters say holds the kernel back (the roofline's unit stays FLOP/s against the VALU peak).
+    `packed_frac`: share of the FP32 peak reached through packed instructions alone (the brute-force filter): a packed
+    instruction holds the SIMD for two issue slots and the counter counts it once, so half of that share is added."""
+    if not q or "valu_issue_fraction" not in q:
         return None
-    if q["valu_utilisation"] >= 0.8:
-        return "VALU issue (SIMDs issue vector instructions >= 80 % of the time)"
-    return ("latency and divergence: SIMDs issue VALU instructions %.0f %% of the time with %.0f %% of the lanes live, "
-            "%.1f waves per SIMD resident; neither HBM nor FP32 throughput is saturated"
-            % (100 * q["valu_utilisation"], 100 * q.get("live_lane_fraction", 0.0), q.get("occupancy_waves_per_simd", 0.0)))
+    if packed_frac:
+        q["valu_issue_fraction_packed_counted_twice"] = q["valu_issue_fraction"] + packed_frac / 2.0
+        q = dict(q, valu_issue_fraction=q["valu_issue_fraction_packed_counted_twice"])
+    if q["valu_issue_fraction"] >= 0.8:
+        return "VALU issue (the SIMDs issue vector instructions at >= 80 % of their peak rate)"
+    return ("latency and divergence: the SIMDs issue VALU instructions at %.0f %% of their peak rate (one wave64 instruction "
+            "per 2 cycles) with %.0f %% of the lanes live, %.1f waves per SIMD resident; neither HBM nor FP32 throughput "
+            "is saturated"
+            % (100 * q["valu_issue_fraction"], 100 * q.get("live_lane_fraction", 0.0), q.get("occupancy_waves_per_simd", 0.0)))
 
 
 # ----------------------------------------------------------------------------------------
@@ -398,7 +408,7 @@ def main(argv=None):
                              "frac": probe_exec / max(probe_ms[dom], 1e-9) / 1e9 / PEAK_FP32_VALU_TFLOPS,
                              "note": "the same launches in a frame that has the GPU to itself (the untimed probe frame); in the timed region "
                                      "launches of two frames overlap, so each takes longer while the frame rate is higher"},
-                "limiter": limiter_of(q), "pmc": q,
+                "limiter": limiter_of(q, ach / PEAK_FP32_VALU_TFLOPS if algo != "bvh" else 0.0), "pmc": q,
                 "scan_equivalent": {"tflops": tf(agg["equiv_flop"], agg["ms"]),
                                     "note": "FLOP the reference's linear scans would have spent on the same rays (44 per ray-triangle test, every "
                                             "triangle per closest-hit ray, up to the first occluder per shadow ray) / the same kernel time: an "
@@ -461,12 +471,12 @@ def brute_leg(fs, device, step, st, workload, warmup=1, steps=2):
             "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": q.get("hbm_bytes_per_launch") if q else None,
             "flop_model": "packed-FP32 filter instructions the kernel executed, from its own counters: per (wave, 128-triangle chunk) 64 pairs x 64 lanes "
                           "x rays per lane x (3 packed mul + 6 or 15 packed FMA; packed FMA = 4 FLOP per lane); min/max/compare instructions "
-                          "and the exact tests of survivors carry no FLOP, so the fraction stays below the VALU utilisation",
+                          "and the exact tests of survivors carry no FLOP, so the fraction stays below the VALU issue fraction",
             "avg_launch_ms": ms[dom] / max(1, launches[dom]), "steps": steps, "warmup": warmup,
             "ms_per_frame": total_ms / steps, "mrays_per_s": rays / max(total_ms, 1e-9) / 1e3,
             "kernel_ms_per_frame": {f"{names[k]} ({KLABEL[k]})": ms[k] / steps for k in range(4)},
             "kernel_frac": {f"{names[k]} ({KLABEL[k]})": tf(flop[k], ms[k]) / PEAK_FP32_VALU_TFLOPS for k in range(3)},
-            "limiter": limiter_of(q), "pmc": q,
+            "limiter": limiter_of(q, ach / PEAK_FP32_VALU_TFLOPS), "pmc": q,
             "scan_equivalent": {"tflops": tf(equiv[dom], ms[dom]),
                                 "note": "44 FLOP per ray-triangle test of the reference's scalar code; the filter answers most tests with "
                                         "fewer instructions, so this exceeds what the silicon executed"}}

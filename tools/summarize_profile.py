@@ -25,6 +25,14 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 for f in newest(f"{src}/trace/*/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+# the default command (python bench.py, as the driver runs it): its kernel stats and its JSON line
+for f in newest(f"{src}/trace_default/*/*kernel_stats.csv"):
+    shutil.copy(f, f"profiles/{tag}_default_cmd_kernel_stats.csv")
+for log, name in ((f"{src}/trace_default.log", f"profiles/{tag}_default_cmd_bench.json"), (f"{src}/trace.log", f"profiles/{tag}_trace_cmd_bench.json")):
+    if os.path.exists(log):
+        lines = [l for l in open(log, errors="replace") if l.startswith('{"metric"')]
+        if lines:
+            open(name, "w").write(lines[-1])
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(int)
 for f in newest(f"{src}/pmc_*/*/*counter_collection.csv"):
@@ -56,8 +64,12 @@ for k, c in tot.items():
          "launches_per_frame": calls[k] / TRACE_FRAMES if k in calls else None}
     if gui:
         m["clock_ghz"] = gui / (ms_frame * PMC_FRAMES * 1e6) if ms_frame else None
-        # one wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts quad-cycles)
-        m["valu_utilisation"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
+        # the SIMDs are 32 lanes wide: with two or more waves resident a SIMD issues one wave64 VALU instruction per
+        # 2 cycles (the 157.3 TFLOP/s FP32 peak is that rate), so the fraction of the issue peak is instructions x 2 /
+        # SIMD-cycles.  SQ_ACTIVE_INST_VALU (quad-cycles a wave spends in VALU instructions, 4 cycles each for a wave
+        # alone) over the same cycles can exceed 1 when waves overlap and is kept under its own name.
+        m["valu_issue_fraction"] = d.get("SQ_INSTS_VALU", 0) * 2.0 / (gui * N_SIMD)
+        m["valu_wave_busy"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
         m["occupancy_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0) * 4.0 / (gui * N_SIMD)
     if "FETCH_SIZE" in d:
         # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reads half of a wide coalesced stream on gfx950 (x2 upper bound)
