@@ -28,6 +28,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Hardware queues of this process (HIP's default is 4; read by the runtime when it starts): every executor with a frame in
+# flight has a stream of its own (two with a side stream), torch and RCCL bring theirs.  Streams beyond the queues share one
+# and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8 with four frames in flight:
+# 0.68 ms with 4 queues, 0.60-0.63 ms with 8 (whole frames: no difference).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test of the reference's scans
 F_NODE = 190.0                       # FLOP per visited hierarchy node (cone term + four enlarged-box slab tests of 46, see bvh_box)
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA: 256 CU x 4 SIMD x 16 lanes x 2 x 2 FLOP x 2.4 GHz)
@@ -268,7 +274,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute", action="store_true", help="leave out the roofline_brute leg (1 warm-up + 2 frames of full scans)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3],
+    ap.add_argument("--lanes-per-frame", type=int, default=0, help="lanes of each executor (0: 1 with frames in flight, else 2)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="executors that take the frames in turn (hierarchy algorithm; 1: one executor with two lanes per frame)")
     ap.add_argument("--selftest-cpu", action="store_true", help="functional check of the multi-process path on CPU (gloo), no GPU")
     args = ap.parse_args(argv)
@@ -304,8 +311,9 @@ def main(argv=None):
     algo = "bvh" if args.algo == "bvh" else "scan"
     # Throughput mode: two executors of the scene, one lane each, take the frames in turn, so that the thinly populated
     # deep recursion levels of one frame run beside the large launches of the next (the scans gain nothing from it).
-    in_flight = args.frames_in_flight if algo == "bvh" else 1
-    pipe = FramesInFlight(fs, device=local_rank, depth=in_flight)
+    # (two at N = 1: the chip is full and more only lengthen every launch; four for the small shares of N > 1)
+    in_flight = (args.frames_in_flight or (2 if world == 1 else 4)) if algo == "bvh" else 1
+    pipe = FramesInFlight(fs, device=local_rank, depth=in_flight, lanes=args.lanes_per_frame or None)
     os.environ.pop("HIPEXEC_NO_CULL", None)
     ex = pipe.ex[0]
     tmax = max_local_tiles(H, world)
@@ -357,12 +365,13 @@ def main(argv=None):
     dom = max(range(3), key=lambda k: probe_ms[k])
     probe_exec = executed_flops_bvh(st, dom, fs.n_sph) if algo == "bvh" else executed_flops_scan(st, dom)
     probe_launches = int(st.launches[dom])
-    agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop")}
+    agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop", "exec_flop_all")}
 
     def account(s):
         agg["rays"] += s.rays
         agg["ms"] += s.kernel_ms[dom]; agg["launches"] += s.launches[dom]
         agg["exec_flop"] += executed_flops_bvh(s, dom, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, dom)
+        agg["exec_flop_all"] += sum((executed_flops_bvh(s, k, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, k)) for k in range(3))
         agg["equiv_flop"] += ref_flops[dom] if ref_flops is not None else scan_equiv_flops(s, dom, fs.n_sph)
 
     fence()
@@ -408,6 +417,10 @@ def main(argv=None):
                              "frac": probe_exec / max(probe_ms[dom], 1e-9) / 1e9 / PEAK_FP32_VALU_TFLOPS,
                              "note": "the same launches in a frame that has the GPU to itself (the untimed probe frame); in the timed region "
                                      "launches of two frames overlap, so each takes longer while the frame rate is higher"},
+                "whole_frame": {"achieved": agg["exec_flop_all"] / max(elapsed, 1e-12) / 1e12, "frac": agg["exec_flop_all"] / max(elapsed, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                "note": "executed FLOP of all three ray classes of this rank / wall time of the timed region: what the chip "
+                                        "delivered while launches of several frames shared it (the per-launch figure above divides by "
+                                        "durations that overlap)"},
                 "limiter": limiter_of(q, ach / PEAK_FP32_VALU_TFLOPS if algo != "bvh" else 0.0), "pmc": q,
                 "scan_equivalent": {"tflops": tf(agg["equiv_flop"], agg["ms"]),
                                     "note": "FLOP the reference's linear scans would have spent on the same rays (44 per ray-triangle test, every "

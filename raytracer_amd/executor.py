@@ -186,10 +186,10 @@ class FramesInFlight:
     itself if the caller has not.  With depth 2 the thinly populated deep recursion levels of one frame run beside the
     camera and first-bounce launches of the next.  The frames are the ones a single executor renders, bit for bit."""
 
-    def __init__(self, scene: FlatScene, device: int = -1, depth: int = 2):
+    def __init__(self, scene: FlatScene, device: int = -1, depth: int = 2, lanes: int | None = None):
         self.ex = [HipExecutor(scene, device=device) for _ in range(depth)]
         for e in self.ex:
-            e.set_lanes(1 if depth > 1 else 2)
+            e.set_lanes(lanes if lanes else (1 if depth > 1 else 2))
         self.stats = [_abi.Stats() for _ in range(depth)]
         self.busy = [False] * depth
         self.next = 0
