@@ -165,7 +165,6 @@ struct hipexec {
     DScene S{};
     DBvh B{};
     bool bvh_ok = false;                      // a hierarchy exists for this scene
-    bool bin_bounce = false;                  // bounce rays of a block queued grouped by direction (HIPEXEC_BIN_BOUNCE)
     bool bvh_default = true;                  // algorithm of calls that do not choose (HIPEXEC_ALGO=scan|bvh)
     bool use_bvh = false;                     // algorithm of the call in progress
     int closest_per_block = 0;                // rays owned by a block of k_bvh_closest_p; 0 = by ray class (HIPEXEC_CLOSEST_PER_BLOCK)
@@ -879,7 +878,7 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     else if (direct)
         LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
-                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn | (spawn && h->bin_bounce ? 2 : 0), next_rays, next_count, n_dev);
+                  h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     else
         LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow<MODE, FUSED>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
                   h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
@@ -1168,7 +1167,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
         g->predict_now = h->predict_now;
         g->block64_below = h->block64_below;
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
-        g->bvh_refill = h->bvh_refill; g->bin_bounce = h->bin_bounce; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
+        g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
         g->worker->submit([&, g, k]() {
             rcs[(size_t)k] = [&]() -> int {
                 HIPCHK(hipSetDevice(g->device));
@@ -1323,7 +1322,6 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) { h->anyhit_lds = atoi(e) != 0; anyhit_lds_set = true; }
         if (const char *e = getenv("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
         if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
-        if (const char *e = getenv("HIPEXEC_BIN_BOUNCE")) h->bin_bounce = atoi(e) != 0;
         if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
         if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));

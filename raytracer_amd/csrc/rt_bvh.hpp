@@ -1092,11 +1092,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_
         }
         if (spawn && next_rays) {
             __shared__ uint32_t append_scratch[5];
-            uint32_t pos;
-            // spawn bit 1: the block's bounce rays are queued grouped by direction (the traversal stacks are free by now
-            // and lend the 65 words the grouping needs)
-            if (BS > 64 && (spawn & 2)) pos = block_append_binned(bounce, bounce ? direction_bin(bd) : 0u, next_count, &stack[0][0]);
-            else pos = block_append(bounce, next_count, append_scratch);
+            uint32_t pos = block_append(bounce, next_count, append_scratch);
             if (bounce) store_ray(next_rays, pos, bo, bd, s, 0u);
         }
     }

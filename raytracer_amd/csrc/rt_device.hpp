@@ -492,49 +492,6 @@ DEV uint32_t block_append(bool pred, uint32_t *counter, uint32_t *scratch) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// Direction bin of a ray, 0..63: the direction is projected onto the octahedron |x|+|y|+|z| = 1, unfolded into the
-// square [-1,1]^2 and cut into 8x8 cells; the cell index interleaves the bits of its two coordinates, so that bins
-// with neighbouring numbers hold neighbouring directions.  Only the order of a queue depends on it, never a result.
-DEV uint32_t direction_bin(f3 d) {
-    float n = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
-    float inv = n > 0.0f ? 1.0f / n : 0.0f;
-    float u = d.x * inv, v = d.z * inv;
-    if (d.y < 0.0f) {                                   // lower half: fold outwards
-        float fu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f), fv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f);
-        u = fu; v = fv;
-    }
-    int a = (int)((u * 0.5f + 0.5f) * 8.0f), b = (int)((v * 0.5f + 0.5f) * 8.0f);
-    a = a < 0 ? 0 : (a > 7 ? 7 : a); b = b < 0 ? 0 : (b > 7 ? 7 : b);          // NaN -> 0
-    uint32_t ua = (uint32_t)a, ub = (uint32_t)b;
-    return (ua & 1u) | ((ub & 1u) << 1) | ((ua & 2u) << 1) | ((ub & 2u) << 2) | ((ua & 4u) << 2) | ((ub & 4u) << 3);
-}
-
-// block_append with the block's entries grouped by `bin` (0..63): the lanes with pred get consecutive slots of the
-// queue, those of bin 0 first.  Rays that leave a block in similar directions then share a wave of the next launch.
-// `lds` is 65 words of LDS that no thread of the block still uses (a barrier comes first); every thread must call.
-DEV uint32_t block_append_binned(bool pred, uint32_t bin, uint32_t *counter, uint32_t *lds) {
-    __syncthreads();
-    if (threadIdx.x < 65u) lds[threadIdx.x] = 0u;
-    __syncthreads();
-    uint32_t rank = 0u;
-    if (pred) rank = atomicAdd(&lds[bin], 1u);
-    __syncthreads();
-    if (threadIdx.x < 64u) {                             // exclusive prefix over the bins, then the block's base
-        uint32_t own = lds[threadIdx.x], inc = own;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-            if ((int)threadIdx.x >= off) inc += up;
-        }
-        uint32_t total = (uint32_t)__shfl((int)inc, 63);
-        uint32_t base = 0u;
-        if (threadIdx.x == 0u && total) base = atomicAdd(counter, total);
-        base = (uint32_t)__shfl((int)base, 0);
-        lds[threadIdx.x] = base + inc - own;
-    }
-    __syncthreads();
-    return lds[bin & 63u] + rank;
-}
-
 DEV unsigned long long wave_sum_u64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;   // valid in lane 0
