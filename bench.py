@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 # and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8 with four frames in flight:
 # 0.68 ms with 4 queues, 0.60-0.63 ms with 8 (whole frames: no difference).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HIPEXEC_KNOBS", "1")     # the library honours HIPEXEC_* knobs (HIPEXEC_NO_CULL of the brute-force leg) only with this set
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test of the reference's scans
 F_NODE = 190.0                       # FLOP per visited hierarchy node (cone term + four enlarged-box slab tests of 46, see bvh_box)

@@ -32,6 +32,14 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Experiment and test knobs come from the environment, but only when HIPEXEC_KNOBS=1 is set as well: a production
+// process does not change behaviour because of a stray variable.
+const char *knob(const char *name)
+{
+    static const bool enabled = [] { const char *e = getenv("HIPEXEC_KNOBS"); return e && e[0] == '1'; }();
+    return enabled ? getenv(name) : nullptr;
+}
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap; va_start(ap, fmt);
@@ -315,7 +323,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     const uint32_t n = S.n_tri;
     B.n = n; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
     B.stack_limit = BVH_STACK;
-    if (const char *e = getenv("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
+    if (const char *e = knob("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
     B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
     h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
@@ -409,7 +417,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     for (uint32_t i = 0; i < s->n_sph; i++) if (std::isfinite(s->sph_radius[i])) rs = std::max(rs, (double)std::fabs(s->sph_radius[i]));
     S.rmax = (float)std::max(1e-3, 1.1 * (std::sqrt(r2) + rs));
     {
-        const char *nf = getenv("HIPEXEC_NO_FILTER");     // verification aid: every pair takes the exact path
+        const char *nf = knob("HIPEXEC_NO_FILTER");     // verification aid: every pair takes the exact path
         S.theta = (nf && nf[0] == '1') ? 3.0e38f : 1.001f;
     }
 
@@ -432,7 +440,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     S.tri_primx = nullptr; S.pair_cam = nullptr; S.pair_gen = nullptr; S.pair_lamp = nullptr; S.chunk_box = nullptr;
     h->lamp_pos_host.assign(s->lamp_pos, s->lamp_pos + 3 * (size_t)s->n_lamp);
     {
-        const char *nc = getenv("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
+        const char *nc = knob("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
     }
     CHK(build_bvh(h, ex, lo, hi, all_finite));
@@ -1245,26 +1253,26 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    if (const char *e = getenv("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
-    if (const char *e = getenv("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
-    if (const char *e = getenv("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
-    if (const char *e = getenv("HIPEXEC_SIMPLE_FROM")) h->simple_from = (uint32_t)strtoul(e, nullptr, 10);
-    if (const char *e = getenv("HIPEXEC_SHADOW_DIRECT")) h->shadow_direct = atoi(e) != 0;
-    if (const char *e = getenv("HIPEXEC_SHADOW_PER_BLOCK")) h->shadow_per_block = (uint32_t)std::max(64, std::min(256, atoi(e) / 64 * 64));
-    if (const char *e = getenv("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
-    if (const char *e = getenv("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("HIPEXEC_BLOCK_CLOSEST")) h->block_closest = atoi(e);
-    if (const char *e = getenv("HIPEXEC_BLOCK_SHADOW")) h->block_shadow = atoi(e);
-    if (const char *e = getenv("HIPEXEC_BLOCK_TAIL")) h->block_tail = atoi(e);
-    if (const char *e = getenv("HIPEXEC_BLOCK64_BELOW")) h->block64_below = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char *e = knob("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = knob("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_SIMPLE_FROM")) h->simple_from = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char *e = knob("HIPEXEC_SHADOW_DIRECT")) h->shadow_direct = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_SHADOW_PER_BLOCK")) h->shadow_per_block = (uint32_t)std::max(64, std::min(256, atoi(e) / 64 * 64));
+    if (const char *e = knob("HIPEXEC_TAIL_MAX")) h->tail_max = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = knob("HIPEXEC_OVERLAP")) h->overlap_levels = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = knob("HIPEXEC_BLOCK_CLOSEST")) h->block_closest = atoi(e);
+    if (const char *e = knob("HIPEXEC_BLOCK_SHADOW")) h->block_shadow = atoi(e);
+    if (const char *e = knob("HIPEXEC_BLOCK_TAIL")) h->block_tail = atoi(e);
+    if (const char *e = knob("HIPEXEC_BLOCK64_BELOW")) h->block64_below = (uint32_t)strtoul(e, nullptr, 10);
     h->n_cnt32 = std::max(8u, n_lamp + 1u);
     HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&h->d_cnt64, CNT64_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&h->d_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc((void **)&h->h_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), hipHostMallocDefault));
-    if (const char *e = getenv("HIPEXEC_PREDICT")) h->predict = atoi(e) != 0;
-    if (const char *e = getenv("HIPEXEC_PREDICT_SPOIL")) h->predict_spoil = atoi(e);   // test hook, see level_end
+    if (const char *e = knob("HIPEXEC_PREDICT")) h->predict = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_PREDICT_SPOIL")) h->predict_spoil = atoi(e);   // test hook, see level_end
     HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_cnt64, CNT64_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
@@ -1315,22 +1323,22 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
     int rc = [&]() -> int {
         CHK(static_scratch_init(device));
         CHK(create_lane_resources(h, scene->n_lamp));
-        if (const char *e = getenv("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
-        if (const char *e = getenv("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
-        if (const char *e = getenv("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
+        if (const char *e = knob("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
+        if (const char *e = knob("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
+        if (const char *e = knob("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
         bool anyhit_lds_set = false;
-        if (const char *e = getenv("HIPEXEC_ANYHIT_LDS")) { h->anyhit_lds = atoi(e) != 0; anyhit_lds_set = true; }
-        if (const char *e = getenv("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
-        if (const char *e = getenv("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
-        if (const char *e = getenv("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
-        if (const char *e = getenv("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
-        if (const char *e = getenv("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
+        if (const char *e = knob("HIPEXEC_ANYHIT_LDS")) { h->anyhit_lds = atoi(e) != 0; anyhit_lds_set = true; }
+        if (const char *e = knob("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
+        if (const char *e = knob("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
+        if (const char *e = knob("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = knob("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
+        if (const char *e = knob("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
         CHK(build_scene(h, scene));
         if (!h->bvh_default || !h->bvh_ok) CHK(ensure_scan_records(h));       // the scans are this executor's algorithm
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each
         // wave reads only the chunks it needs and the scalar path wins
         if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
-        if (const char *e = getenv("HIPEXEC_LANES")) h->max_lanes = std::max(1, std::min(8, atoi(e)));      // 1: no further lanes
+        if (const char *e = knob("HIPEXEC_LANES")) h->max_lanes = std::max(1, std::min(8, atoi(e)));      // 1: no further lanes
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         // (further lanes are made by the first frame that uses them, see more_lanes: streams are bound to the
         // process's few hardware queues in the order they are created, and an executor that is used with one lane,

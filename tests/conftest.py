@@ -1,4 +1,6 @@
 import os
+
+os.environ.setdefault("HIPEXEC_KNOBS", "1")      # the library honours its HIPEXEC_* experiment / test knobs only with this set
 import sys
 
 import pytest

@@ -1,5 +1,6 @@
 """Time the per-frame executor pattern of ray_tracer_cl.cpp:14 (create, render one frame, destroy)."""
 import os, sys, time
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracer_amd import scenegen, _abi

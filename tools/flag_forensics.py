@@ -2,6 +2,7 @@
 python tools/flag_forensics.py <path to libhip_executor*.so>.  Used to compare the build whose per-lane traversal flags
 are `bool` (-DRT_FLAG_BOOL) with the shipped one (32-bit words)."""
 import os, sys
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracer_amd import _abi

@@ -1,5 +1,6 @@
 """Print per-frame kernel-class times of a workload (diagnostic)."""
 import sys, os
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import scenegen
 from raytracer_amd.executor import HipExecutor

@@ -1,6 +1,7 @@
 """Renders `frames` frames of rank 0's share (tile_step G) with K frames in flight and nothing else, for tracing:
 python tools/pipeline_run.py c2 8 4 40"""
 import os, sys
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracer_amd import scenegen

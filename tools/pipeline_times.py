@@ -1,6 +1,7 @@
 """Throughput of rank 0's share (G = 1, 2, 4, 8) with frames in flight (executors of one scene, one lane each, taking
 frames in turn) against one executor with two lanes: python tools/pipeline_times.py c2 [depths of flight ...]"""
 import os, sys, time
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracer_amd import scenegen

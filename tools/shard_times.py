@@ -1,6 +1,7 @@
 """Time one rank's share of a frame for G = 1, 2, 4, 8 (tile_first = 0, tile_step = G) on one GPU:
 the compute part of the strong-scaling curve without the gather."""
 import os, sys, time
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracer_amd import scenegen, _abi

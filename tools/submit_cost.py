@@ -1,6 +1,7 @@
 """Host time of enqueueing one frame (hipexec_render_device returns before the GPU has finished) against the frame's
 GPU time, for rank 0's share at G = 1, 2, 4, 8: python tools/submit_cost.py c2"""
 import os, sys, time
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracer_amd import scenegen

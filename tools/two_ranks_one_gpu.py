@@ -2,6 +2,7 @@
 frames in flight and L lanes per frame: what queue contention between processes looks like where only one GPU is at hand.
 python tools/two_ranks_one_gpu.py c2     (parent: starts the workers for several settings and prints the frame periods)"""
 import os, subprocess, sys, time
+import os as _os; _os.environ.setdefault("HIPEXEC_KNOBS", "1")   # the HIPEXEC_* experiment knobs are honoured only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
