@@ -322,8 +322,13 @@ def main(argv=None):
     st = _abi.Stats()
     frame = None
 
+    gathered = [None] * in_flight             # per slot: event on torch's stream after the gather that last read outs[slot]
+
     def submit(time_kernels, a=None):
         k = pipe.next
+        if gathered[k] is not None:           # the executor writes outs[k] from its own streams: not before that gather has read it
+            gathered[k].synchronize()
+            gathered[k] = None
         return pipe.submit(W, H, outs[k].data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
                            time_kernels=time_kernels, algo=a or algo)
 
@@ -331,6 +336,8 @@ def main(argv=None):
         nonlocal frame
         s = pipe.collect(slot)                       # waits for the frame's kernels (the executor's own streams)
         frame = gather_frame(outs[slot], H)          # RCCL gather to rank 0 + de-interleave (torch's stream)
+        gathered[slot] = torch.cuda.Event()
+        gathered[slot].record()
         return s
 
     def step(time_kernels, exe=None, a=None):
@@ -422,6 +429,12 @@ def main(argv=None):
                                 "note": "executed FLOP of all three ray classes of this rank / wall time of the timed region: what the chip "
                                         "delivered while launches of several frames shared it (the per-launch figure above divides by "
                                         "durations that overlap)"},
+                "unfused_ceiling": {"tflops": PEAK_FP32_VALU_TFLOPS / 2.0,
+                                    "note": "the peak counts a fused multiply-add as 2 FLOP per lane and issue slot; the exact arithmetic of the "
+                                            "path must round after every multiply and every add like the reference's x86 build "
+                                            "(-ffp-contract=off), 1 FLOP per lane and slot, so half the peak is the most this code could reach "
+                                            "with every lane live and every slot carrying a FLOP; compares, min/max and selects (about 40 % of "
+                                            "a node step) carry none"},
                 "limiter": limiter_of(q, ach / PEAK_FP32_VALU_TFLOPS if algo != "bvh" else 0.0), "pmc": q,
                 "scan_equivalent": {"tflops": tf(agg["equiv_flop"], agg["ms"]),
                                     "note": "FLOP the reference's linear scans would have spent on the same rays (44 per ray-triangle test, every "
