@@ -114,6 +114,11 @@ def pmc_quote(kernel_class, workload, algo):
             # fraction of the VALU issue peak: a SIMD (32 lanes wide) issues one wave64 instruction per 2 cycles;
             # GRBM_GUI_ACTIVE is the sum over the 8 XCDs, 1024 SIMDs on the chip
             q["valu_issue_fraction"] = c["SQ_INSTS_VALU"] * 2.0 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU"):
+            # rocprofiler-sdk's derived metrics for gfx950 (counter_defs.yaml): VALUBusy = 100 * SQ_ACTIVE_INST_VALU / CU_NUM /
+            # GRBM_GUI_ACTIVE (per XCD), VALUUtilization = 100 * SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+            q["rocprof_VALUBusy_pct"] = 100.0 * c["SQ_ACTIVE_INST_VALU"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+            q["rocprof_VALUUtilization_pct"] = 100.0 * c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
         if c.get("SQ_ACTIVE_INST_VALU"):
             q["live_lane_fraction"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
         if c.get("SQ_WAVE_CYCLES"):
@@ -136,9 +141,10 @@ def limiter_of(q, packed_frac=0.0):
     if q["valu_issue_fraction"] >= 0.8:
         return "VALU issue (the SIMDs issue vector instructions at >= 80 % of their peak rate)"
     return ("latency and divergence: the SIMDs issue VALU instructions at %.0f %% of their peak rate (one wave64 instruction "
-            "per 2 cycles) with %.0f %% of the lanes live, %.1f waves per SIMD resident; neither HBM nor FP32 throughput "
-            "is saturated"
-            % (100 * q["valu_issue_fraction"], 100 * q.get("live_lane_fraction", 0.0), q.get("occupancy_waves_per_simd", 0.0)))
+            "per 2 cycles; rocprof's VALUBusy, which prices an instruction at 4 cycles: %.0f %%) with %.0f %% of the lanes live, "
+            "%.1f waves per SIMD resident; neither HBM nor FP32 throughput is saturated"
+            % (100 * q["valu_issue_fraction"], q.get("rocprof_VALUBusy_pct", 0.0), 100 * q.get("live_lane_fraction", 0.0),
+               q.get("occupancy_waves_per_simd", 0.0)))
 
 
 # ----------------------------------------------------------------------------------------

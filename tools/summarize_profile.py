@@ -70,6 +70,13 @@ for k, c in tot.items():
         # alone) over the same cycles can exceed 1 when waves overlap and is kept under its own name.
         m["valu_issue_fraction"] = d.get("SQ_INSTS_VALU", 0) * 2.0 / (gui * N_SIMD)
         m["valu_wave_busy"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
+        # rocprofiler-sdk's own derived metrics for gfx950 (share/rocprofiler-sdk/counter_defs.yaml):
+        #   VALUBusy = 100 * sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE)   (= valu_wave_busy in percent; it can
+        #   exceed 100 because two waves of a SIMD overlap their VALU instructions)
+        #   VALUUtilization = 100 * sum(SQ_THREAD_CYCLES_VALU) / (sum(SQ_ACTIVE_INST_VALU) * 64)   (live lanes)
+        m["rocprof_VALUBusy_pct"] = 100.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / 256.0 / gui
+        if d.get("SQ_ACTIVE_INST_VALU"):
+            m["rocprof_VALUUtilization_pct"] = 100.0 * d.get("SQ_THREAD_CYCLES_VALU", 0) / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
         m["occupancy_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0) * 4.0 / (gui * N_SIMD)
     if "FETCH_SIZE" in d:
         # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reads half of a wide coalesced stream on gfx950 (x2 upper bound)
