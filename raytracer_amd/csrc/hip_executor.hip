@@ -229,6 +229,7 @@ struct hipexec {
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
+    uint32_t shadow_waves6_from = 8u;         // HIPEXEC_SHADOW_WAVES6_FROM: lamps from which the shadow kernel compiled for 6 waves per SIMD is used
     uint32_t simple_from = 0u;                // HIPEXEC_SIMPLE_FROM: closest-hit launches of at least this many rays take one ray per lane
                                               // (k_bvh_closest); smaller ones the kernel whose lanes fetch a new ray when theirs is decided
     bool shadow_direct = true;                // HIPEXEC_SHADOW_DIRECT=0: shadow rays through the block's list in LDS (k_bvh_shadow)
@@ -881,7 +882,22 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
     const uint32_t blocks = (n + per_block - 1) / per_block;
     const float4 *nodes_sc = h->uniform_fetch ? h->B.nodes : nullptr;
     const bool direct = h->shadow_direct || h->S.ao;       // the occlusion rays of HIPEXEC_FLAG_AO exist in the direct form only
-    if (direct && (h->block_shadow == 64 || n <= h->block64_below))
+    const bool one_wave = h->block_shadow == 64 || n <= h->block64_below;
+    if (direct && h->S.ao && FUSED && MODE == HIPEXEC_MODE_CPU) {
+        if (one_wave)
+            LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64, true>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
+                      h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
+        else
+            LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256, true>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
+                      h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
+    } else if (direct && h->S.n_lamp >= h->shadow_waves6_from) {          // many lamps: the variant compiled for six waves per SIMD
+        if (one_wave)
+            LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64, false, 6>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
+                      h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
+        else
+            LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256, false, 6>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
+                      h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
+    } else if (direct && one_wave)
         LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
                   h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     else if (direct)
@@ -1175,7 +1191,7 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
         g->predict_now = h->predict_now;
         g->block64_below = h->block64_below;
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
-        g->bvh_refill = h->bvh_refill; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
+        g->bvh_refill = h->bvh_refill; g->shadow_waves6_from = h->shadow_waves6_from; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
         g->worker->submit([&, g, k]() {
             rcs[(size_t)k] = [&]() -> int {
                 HIPCHK(hipSetDevice(g->device));
@@ -1257,6 +1273,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     if (const char *e = knob("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
     if (const char *e = knob("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
     if (const char *e = knob("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_SHADOW_WAVES6_FROM")) h->shadow_waves6_from = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = knob("HIPEXEC_SIMPLE_FROM")) h->simple_from = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = knob("HIPEXEC_SHADOW_DIRECT")) h->shadow_direct = atoi(e) != 0;
     if (const char *e = knob("HIPEXEC_SHADOW_PER_BLOCK")) h->shadow_per_block = (uint32_t)std::max(64, std::min(256, atoi(e) / 64 * 64));

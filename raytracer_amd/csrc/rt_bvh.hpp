@@ -29,7 +29,16 @@ namespace rt {
 constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 2;
-constexpr int BVH_STACK = 24;                   // LDS stack entries per lane (a node pushes up to three)
+#ifndef RT_BVH_STACK
+#define RT_BVH_STACK 24
+#endif
+#ifndef RT_CLOSEST_WAVES
+#define RT_CLOSEST_WAVES 6
+#endif
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 5
+#endif
+constexpr int BVH_STACK = RT_BVH_STACK;         // LDS stack entries per lane (a node pushes up to three)
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
 constexpr float BVH_TIGHT = 4.0e-6f;
@@ -771,7 +780,7 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
 // BS = threads per block.  A block's LDS (its stacks) is released only when its last wave has finished, and rays
 // differ widely in length: with one wave per block no finished wave keeps memory from a waiting block.
 template <int MODE, int BS>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(RT_CLOSEST_WAVES))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                      float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                      int klass, const uint32_t *__restrict__ n_dev)
 {
@@ -1001,8 +1010,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // to one lamp after the other; lanes whose sample casts no ray to the lamp at hand sit that lamp out.  No barriers and
 // no LDS besides the stacks, but the waves are only as full as the fraction of samples that face the lamp.
 // ---------------------------------------------------------------------------------------
-template <int MODE, bool FUSED, int BS>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
+// AO: the kernel also traces the occlusion rays of HIPEXEC_FLAG_AO (a variant of its own, so that the default kernel does
+// not carry that loop's registers)
+// WAVES: waves per SIMD the kernel is compiled for.  5 (96 VGPRs) for few lamps; with many lamps the kernel is one long
+// run of traversals whose latency is worth a sixth wave although the compiler then keeps 31 values in scratch (80 VGPRs):
+// C5 (16 lamps) 25.6 -> 24.3 ms, C2 / C3 / C4 (1-2 lamps) 1-2 % slower at 6.
+template <int MODE, bool FUSED, int BS, bool AO = false, int WAVES = RT_SHADOW_WAVES>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
                                                     uint32_t *__restrict__ occl, uint32_t lw,
                                                     unsigned long long *__restrict__ counters, uint32_t per_block,
@@ -1062,7 +1076,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // HIPEXEC_FLAG_AO: the occlusion rays of computeAmbientOcclusion (ray_tracer.cpp:406-424), one after the other like the
     // lamp rays; the sum is formed in the reference's order
     float ao = 0.0f;
-    if (FUSED && MODE == HIPEXEC_MODE_CPU && S.ao) {
+    if (AO && FUSED && MODE == HIPEXEC_MODE_CPU && S.ao) {
         const f3 realNorm = dotWithDir < 0.0f ? sf.N : -sf.N;
         for (uint32_t i = 0; i < (uint32_t)HIPEXEC_AO_RAYS; i++) {
             if (hit) {
