@@ -5,6 +5,7 @@
 // and integration/scene_flatten.hpp can be compiled and run in this repository, where the
 // reference's headers (and glm) are not available.  No reference code is compiled with it.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <memory>
 #include <string>
@@ -53,6 +54,14 @@ public:
     float *getPixel(int x, int y) const { return const_cast<float *>(d.data()) + ((size_t)W * y + x) * 3; }
     int getHeight() const { return H; }
     int getWidth() const { return W; }
+    void clear() { std::fill(d.begin(), d.end(), 0.0f); }
+    void copyImageTo(int x, int y, const image_bitmap &img) {               // image_bitmap.h:67-74
+        for (int i = 0; i < img.getHeight() && i + y < H; i++)
+            for (int j = 0; j < img.getWidth() && j + x < W; j++) {
+                const float *p = img.getPixel(j, i);
+                setPixel(x + j, y + i, p[0], p[1], p[2]);
+            }
+    }
 };
 
 class OpenClExecutor;

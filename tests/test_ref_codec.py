@@ -104,3 +104,36 @@ def test_committed_fixtures_are_what_the_reference_build_says(expected, tmp_path
     raw = open(tmp, "rb").read()
     n = struct.unpack("<I", raw[:4])[0]
     assert np.array_equal(np.frombuffer(raw, np.uint32, n, 4), expected["json/floats"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# framebuffer class: image_bitmap.h compiles on its own, so the reference's class itself wrote tests/golden/ref_bitmap.bin
+# ---------------------------------------------------------------------------------------------------------
+REF_BITMAP = os.path.join(ROOT, "oracle", "_ref", "ref_bitmap")
+BITMAP_GOLD = os.path.join(ROOT, "tests", "golden", "ref_bitmap.bin")
+
+
+def test_stand_in_framebuffer_equals_the_references_class(tmp_path):
+    """The class the drop-in's unit test is compiled against (tests/cpp/mock_reference.h) leaves the same bytes as the
+    reference's image_bitmap (image_bitmap.h:11-75) after the same calls: layout, dropped out-of-range pixels, clipped
+    copies, clear."""
+    exe = str(tmp_path / "stand_in_bitmap")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", '-DBITMAP_STAND_IN="mock_reference.h"', "-I", os.path.join(ROOT, "tests", "cpp"),
+                    "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "oracle", "ref_bitmap_harness.cpp")], check=True)
+    out = str(tmp_path / "o.bin")
+    subprocess.run([exe, out], check=True)
+    got, want = open(out, "rb").read(), open(BITMAP_GOLD, "rb").read()
+    assert len(want) > 2000 and got == want
+    # the layout the device code and hipexec_render_rect assume: float RGB, row-major, data[(y*W + x)*3 + c]
+    w, h = struct.unpack("<ii", want[:8])
+    first = np.frombuffer(want, np.float32, w * h * 3, 8)
+    second = np.frombuffer(want, np.float32, w * h * 3, 8 + 4 * w * h * 3 + 8).reshape(h, w, 3)
+    assert (w, h) == (7, 5) and not first.any()
+    assert second[3, 2, 0] == 100.0 * 3 + 2 and second[3, 2, 1] == 1.0 and second[3, 2, 2] == -3.0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BITMAP), reason="reference build (oracle/_ref) only exists in the build container")
+def test_committed_framebuffer_fixture_is_what_the_reference_class_does(tmp_path):
+    out = str(tmp_path / "o.bin")
+    subprocess.run([REF_BITMAP, out], check=True)
+    assert open(out, "rb").read() == open(BITMAP_GOLD, "rb").read()
