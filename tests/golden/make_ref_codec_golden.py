@@ -198,7 +198,8 @@ def main():
           + ", ".join(f"{k}={v}" for k, v in errs.items() if v))
     print("floats:", expected["json/floats"][:8], "... ints:", expected["json/ints"][:12])
     # the reference's framebuffer class through its fixed script of calls (oracle/ref_bitmap_harness.cpp)
-    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_bitmap"), os.path.join(HERE, "ref_bitmap.bin")], check=True)
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_bitmap"), os.path.join(HERE, "ref_bitmap.bin"),
+                    os.path.join(HERE, "ref_config.json")], check=True)
 
 
 if __name__ == "__main__":

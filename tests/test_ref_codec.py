@@ -134,6 +134,33 @@ def test_stand_in_framebuffer_equals_the_references_class(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(REF_BITMAP), reason="reference build (oracle/_ref) only exists in the build container")
 def test_committed_framebuffer_fixture_is_what_the_reference_class_does(tmp_path):
-    out = str(tmp_path / "o.bin")
-    subprocess.run([REF_BITMAP, out], check=True)
+    out, cfg = str(tmp_path / "o.bin"), str(tmp_path / "c.json")
+    subprocess.run([REF_BITMAP, out, cfg], check=True)
     assert open(out, "rb").read() == open(BITMAP_GOLD, "rb").read()
+    assert open(cfg).read() == open(CONFIG_GOLD).read()
+
+
+CONFIG_GOLD = os.path.join(ROOT, "tests", "golden", "ref_config.json")
+
+
+def test_constants_and_eps_comparisons_are_the_references():
+    """config.h:8-20 as the reference's own preprocessor and compiler see it (written by oracle/_ref/ref_bitmap): the
+    constants this build takes over, and the float-equivalent forms of the comparisons against the double EPS."""
+    import json
+    import re
+    c = json.load(open(CONFIG_GOLD))
+    assert c["EPS"] == 0.0001 and c["sizeof_EPS"] == 8                      # a double literal: floats are promoted
+    # x < EPS  <=>  x <= 0.0001f   and   x > EPS  <=>  x > 0.0001f   for the floats around 1e-4 (the forms rt_device.hpp and
+    # the oracle use, ray_tracer.cpp:191,305,311)
+    assert c["eps_float_bits"] == int(np.float32(0.0001).view(np.uint32))
+    for lt, gt, le_f in c["around_eps"]:
+        assert lt == le_f and gt == 1 - le_f
+    hdr = open(os.path.join(ROOT, "include", "hip_executor.h")).read()
+    assert int(re.search(r"#define\s+HIPEXEC_AO_RAYS\s+(\d+)", hdr).group(1)) == c["AO_RAYS_COUNT"]
+    orc = open(os.path.join(ROOT, "oracle", "rt_oracle.c")).read()
+    assert "HIPEXEC_AO_RAYS" in orc                                          # the oracle takes the count from the same header
+    # what the reference's default build does, which is what the default flags of this build do
+    assert c["GPU_ACCELERATION"] and not c["ENABLE_AO"] and not c["ENABLE_REFLECTION"] and not c["RENDER_PARALLEL"]
+    assert (c["WIDTH"], c["HEIGHT"], c["SUB_BLOCK_WIDTH"], c["SUB_BLOCK_HEIGHT"], c["MAX_REFLECTION_DEPTH"]) == (800, 600, 48, 48, 2)
+    drv = open(os.path.join(ROOT, "tests", "cpp", "dropin_driver.cpp")).read()
+    assert "48" in drv                                                       # the block walk of the drop-in's unit test uses the same block size
