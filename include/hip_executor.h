@@ -224,8 +224,18 @@ typedef struct hipexec_hit {
  */
 int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device);
 
-/* Replaces OpenClExecutor::~OpenClExecutor (opencl_executor.cpp:110-147). NULL is a no-op. */
+/* Replaces OpenClExecutor::~OpenClExecutor (opencl_executor.cpp:110-147). NULL is a no-op.
+ * The executor's device memory, pinned host memory and streams go back to a pool of the library, from which the next
+ * hipexec_create() on that device is served: the reference makes and destroys an executor inside every renderSceneCl
+ * call (ray_tracer_cl.cpp:14), and allocation would otherwise cost more than the frame. */
 void hipexec_destroy(hipexec_t *h);
+
+/*
+ * Returns what the library's pool holds for `device` (-1: every device) to the driver.  No counterpart in the
+ * reference.  The pool keeps at most 8 GiB per device (environment HIPEXEC_POOL_MB together with HIPEXEC_KNOBS=1
+ * changes that, 0 turns the pool off); memory of live executors is not affected.
+ */
+int hipexec_trim(int device);
 
 /*
  * Use `stream` (a hipStream_t) for all work of later calls instead of the executor's own

@@ -102,6 +102,7 @@ ROWS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)
 PROTOTYPES = {
     "hipexec_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(SceneDesc), C.c_int]),
     "hipexec_destroy": (None, [C.c_void_p]),
+    "hipexec_trim": (C.c_int, [C.c_int]),
     "hipexec_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hipexec_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "hipexec_set_algorithm": (C.c_int, [C.c_void_p, C.c_int]),

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
@@ -17,8 +18,10 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "hip_executor.h"
@@ -40,6 +43,21 @@ const char *knob(const char *name)
     return enabled ? getenv(name) : nullptr;
 }
 
+// HIPEXEC_TRACE_CREATE=1 (with HIPEXEC_KNOBS=1): host time of the stages of hipexec_create / hipexec_destroy on stderr
+struct StageTrace {
+    bool on; std::chrono::steady_clock::time_point t0, last;
+    StageTrace() : on(false) { const char *e = knob("HIPEXEC_TRACE_CREATE"); on = e && e[0] == '1'; t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hipexec] %-28s +%7.1f us (at %8.1f)\n", what, std::chrono::duration<double, std::micro>(now - last).count(),
+                std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
+thread_local StageTrace *g_stage = nullptr;
+#define STAGE(what) do { if (g_stage) g_stage->mark(what); } while (0)
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap; va_start(ap, fmt);
@@ -59,17 +77,133 @@ int fail(int code, const char *fmt, ...)
 #define CHK(expr) do { int r_ = (expr); if (r_ != HIPEXEC_OK) return r_; } while (0)
 
 // grow-only device buffer
+// ---------------------------------------------------------------------------------------------------------
+// Process-wide pool of device memory, pinned host memory and streams.  The reference builds and destroys its executor
+// inside every renderSceneCl call (ray_tracer_cl.cpp:14), and so does the drop-in: with hipMalloc / hipFree /
+// hipHostMalloc / hipStreamCreate paid every time, create + destroy cost more than the frame.  Freed blocks are kept per
+// device and size class (sizes round up to m * 2^k, m = 8..15: at most 12.5 % over) and handed to the next executor;
+// beyond HIPEXEC_POOL_MB (default 8192) of cached bytes per device, or with HIPEXEC_POOL_MB=0, blocks go back to the
+// driver.  hipexec_trim() returns everything that is cached.  What the pool holds at process exit is left to the driver.
+// Blocks are reused without clearing: every consumer writes what it reads (as with fresh hipMalloc memory).
+// ---------------------------------------------------------------------------------------------------------
+struct MemPool {
+    struct Side { std::multimap<size_t, void *> free; std::unordered_map<void *, size_t> size; size_t cached = 0; };
+    struct Dev { Side dev, pin; std::vector<hipStream_t> streams; };
+    std::mutex m;
+    Dev d[64];
+    size_t cap_bytes;
+    MemPool() { const char *e = knob("HIPEXEC_POOL_MB"); cap_bytes = (size_t)(e ? std::max(0L, atol(e)) : 8192L) << 20; }
+    static size_t size_class(size_t bytes) {
+        if (bytes <= 4096) return 4096;
+        int k = 63 - __builtin_clzll((unsigned long long)bytes);          // 2^k <= bytes
+        size_t step = (size_t)1 << (k - 3);
+        return (bytes + step - 1) / step * step;
+    }
+};
+MemPool &pool() { static MemPool *p = new MemPool(); return *p; }           // never destroyed: no ordering against the HIP runtime's teardown
+
+int pool_alloc(int device, bool pinned, size_t bytes, void **out)
+{
+    MemPool &P = pool();
+    const size_t cls = MemPool::size_class(bytes);
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(P.m);
+        MemPool::Side &sd = pinned ? P.d[device].pin : P.d[device].dev;
+        auto it = sd.free.find(cls);
+        if (it != sd.free.end()) { *out = it->second; sd.free.erase(it); sd.cached -= cls; return HIPEXEC_OK; }
+    }
+    void *p = nullptr;
+    hipError_t e = pinned ? hipHostMalloc(&p, cls, hipHostMallocDefault) : hipMalloc(&p, cls);
+    if (e != hipSuccess && device >= 0 && device < 64) {                        // out of memory: give the cache back and try once more
+        {
+            std::lock_guard<std::mutex> lk(P.m);
+            MemPool::Side &sd = pinned ? P.d[device].pin : P.d[device].dev;
+            for (auto &kv : sd.free) { if (pinned) (void)hipHostFree(kv.second); else (void)hipFree(kv.second); sd.size.erase(kv.second); }
+            sd.free.clear(); sd.cached = 0;
+        }
+        (void)hipGetLastError();
+        e = pinned ? hipHostMalloc(&p, cls, hipHostMallocDefault) : hipMalloc(&p, cls);
+    }
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? HIPEXEC_E_NOMEM : HIPEXEC_E_DEVICE, "%s of %zu bytes: %s",
+                                     pinned ? "hipHostMalloc" : "hipMalloc", cls, hipGetErrorString(e));
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(P.m);
+        (pinned ? P.d[device].pin : P.d[device].dev).size[p] = cls;
+    }
+    *out = p;
+    return HIPEXEC_OK;
+}
+
+void pool_free(int device, bool pinned, void *p)
+{
+    if (!p) return;
+    MemPool &P = pool();
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(P.m);
+        MemPool::Side &sd = pinned ? P.d[device].pin : P.d[device].dev;
+        auto it = sd.size.find(p);
+        if (it != sd.size.end() && sd.cached + it->second <= P.cap_bytes) { sd.free.emplace(it->second, p); sd.cached += it->second; return; }
+        if (it != sd.size.end()) sd.size.erase(it);
+    }
+    if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+}
+
+int pool_stream(int device, hipStream_t *out)
+{
+    MemPool &P = pool();
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(P.m);
+        std::vector<hipStream_t> &v = P.d[device].streams;
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return HIPEXEC_OK; }
+    }
+    HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return HIPEXEC_OK;
+}
+
+// the stream must be idle (its owner synchronised it)
+void pool_stream_back(int device, hipStream_t s)
+{
+    if (!s) return;
+    MemPool &P = pool();
+    if (device >= 0 && device < 64 && P.cap_bytes) {
+        std::lock_guard<std::mutex> lk(P.m);
+        if (P.d[device].streams.size() < 32) { P.d[device].streams.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
+void pool_trim(int device)
+{
+    MemPool &P = pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    for (int dv = 0; dv < 64; dv++) {
+        if (device >= 0 && dv != device) continue;
+        MemPool::Dev &D = P.d[dv];
+        if (D.dev.free.empty() && D.pin.free.empty() && D.streams.empty()) continue;
+        (void)hipSetDevice(dv);
+        for (auto &kv : D.dev.free) { (void)hipFree(kv.second); D.dev.size.erase(kv.second); }
+        for (auto &kv : D.pin.free) { (void)hipHostFree(kv.second); D.pin.size.erase(kv.second); }
+        D.dev.free.clear(); D.pin.free.clear(); D.dev.cached = D.pin.cached = 0;
+        for (hipStream_t st : D.streams) (void)hipStreamDestroy(st);
+        D.streams.clear();
+    }
+}
+
 struct Buf {
-    void *p = nullptr; size_t cap = 0;
+    void *p = nullptr; size_t cap = 0; int device = -1;
     int reserve(size_t bytes) {
         if (bytes <= cap) return HIPEXEC_OK;
-        if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        HIPCHK(hipMalloc(&p, want));
+        if (device < 0) HIPCHK(hipGetDevice(&device));
+        if (p) {                                  // growing: work queued on the old block must be over before another owner can get it
+            HIPCHK(hipDeviceSynchronize());
+            pool_free(device, false, p); p = nullptr; cap = 0;
+        }
+        size_t want = MemPool::size_class(bytes + 256);
+        CHK(pool_alloc(device, false, want, &p));
         cap = want;
         return HIPEXEC_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) pool_free(device, false, p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -182,6 +316,7 @@ struct hipexec {
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;         // chunks of the scene arena
     char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    void *build_tmp = nullptr;                // temporaries of the hierarchy build, until the build has been waited for
     float *d_tri_p = nullptr, *d_tri_e1 = nullptr, *d_tri_e2 = nullptr;   // the caller's triangle arrays on the device (set-up kernels read them)
     std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
     bool scan_ready = false;                  // the scan algorithm's records exist (ensure_scan_records)
@@ -264,7 +399,7 @@ int scene_alloc(hipexec *h, size_t bytes, void **out)
     if (h->arena_used + bytes > h->arena_cap) {
         size_t want = std::max(bytes, CHUNK);
         void *p = nullptr;
-        HIPCHK(hipMalloc(&p, want));
+        CHK(pool_alloc(h->device, false, want, &p));
         h->scene_allocs.push_back(p);
         h->arena = static_cast<char *>(p); h->arena_cap = want; h->arena_used = 0;
     }
@@ -346,7 +481,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     size_t used = 0;
     auto carve = [&](size_t bytes) -> void * { void *p = block + used; used += (bytes + 255) / 256 * 256; return p; };
     const size_t total = 2 * (8 * (size_t)n + 256) + 3 * (8 * (size_t)n + 256) + (4 * (size_t)n + 256) + 4 * (32 * (size_t)n + 256) + tmp_bytes + 256;
-    HIPCHK(hipMalloc((void **)&block, total));
+    CHK(pool_alloc(h->device, false, total, (void **)&block));
     int rc = [&]() -> int {
         keys_a = (unsigned long long *)carve(8 * (size_t)n); keys_b = (unsigned long long *)carve(8 * (size_t)n);
         child = (uint32_t *)carve(8 * (size_t)n); parent = (uint32_t *)carve(8 * (size_t)n); range = (uint32_t *)carve(8 * (size_t)n);
@@ -370,15 +505,18 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         if (n >= 2) {
             hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(k_bvh_refit, grid, blk, 0, h->stream, n, child, parent, arrived, box_lo, box_hi, nrm_lo, nrm_hi);
+            hipLaunchKernelGGL(k_bvh_refit, dim3((n + REFIT_BLOCK - 1) / REFIT_BLOCK), dim3(REFIT_BLOCK), 0, h->stream, n, child, parent, range, arrived,
+                               box_lo, box_hi, nrm_lo, nrm_hi);
+            hipLaunchKernelGGL(k_bvh_refit_top, dim3(1), dim3(1024), 0, h->stream, n, child, range, arrived, box_lo, box_hi, nrm_lo, nrm_hi);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, child, range, box_lo, box_hi, nrm_lo, nrm_hi, nodes);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
         return HIPEXEC_OK;
     }();
-    (void)hipFree(block);
+    // the kernels above are only queued: the block is released by build_scene after its one synchronisation (or by
+    // hipexec_destroy, which synchronises first, if anything fails before that)
+    h->build_tmp = block;
     return rc;
 }
 
@@ -403,9 +541,53 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
             else all_finite = false;
         }
     };
-    for (uint32_t i = 0; i < s->n_tri; i++) {
-        const float *p = s->tri_p + 3 * (size_t)i, *a = s->tri_e1 + 3 * (size_t)i, *b = s->tri_e2 + 3 * (size_t)i;
-        grow(p[0], p[1], p[2]); grow(p[0] + a[0], p[1] + a[1], p[2] + a[2]); grow(p[0] + b[0], p[1] + b[1], p[2] + b[2]);
+    {
+        // fast pass in float (the vertices are floats, so their minima and maxima are exact): usable if every coordinate is
+        // finite and below 1e18; otherwise the careful pass below, which leaves such coordinates out, does the work
+        // (the pass streams 36 bytes per triangle from host memory, which one core does at about 10 GB/s: large scenes
+        // are split over a few threads)
+        struct Part { float lo[3], hi[3]; int bad; };
+        auto scan = [&](size_t t0, size_t t1, Part &pt) {
+            float l0 = 3.0e38f, l1 = 3.0e38f, l2 = 3.0e38f, h0 = -3.0e38f, h1 = -3.0e38f, h2 = -3.0e38f;
+            int bad = 0;
+            const float *P = s->tri_p, *A = s->tri_e1, *Bv = s->tri_e2;
+            for (size_t i = 3 * t0; i < 3 * t1; i += 3) {
+                const float p0 = P[i], p1 = P[i + 1], p2 = P[i + 2];
+                const float a0 = p0 + A[i], a1 = p1 + A[i + 1], a2 = p2 + A[i + 2];
+                const float b0 = p0 + Bv[i], b1 = p1 + Bv[i + 1], b2 = p2 + Bv[i + 2];
+                l0 = std::min(l0, std::min(p0, std::min(a0, b0))); h0 = std::max(h0, std::max(p0, std::max(a0, b0)));
+                l1 = std::min(l1, std::min(p1, std::min(a1, b1))); h1 = std::max(h1, std::max(p1, std::max(a1, b1)));
+                l2 = std::min(l2, std::min(p2, std::min(a2, b2))); h2 = std::max(h2, std::max(p2, std::max(a2, b2)));
+                // NaN, Inf and huge values fail `< 1e18f`
+                bad |= !(std::fabs(p0) < 1e18f) | !(std::fabs(p1) < 1e18f) | !(std::fabs(p2) < 1e18f) | !(std::fabs(a0) < 1e18f) |
+                       !(std::fabs(a1) < 1e18f) | !(std::fabs(a2) < 1e18f) | !(std::fabs(b0) < 1e18f) | !(std::fabs(b1) < 1e18f) |
+                       !(std::fabs(b2) < 1e18f);
+            }
+            pt.lo[0] = l0; pt.lo[1] = l1; pt.lo[2] = l2; pt.hi[0] = h0; pt.hi[1] = h1; pt.hi[2] = h2; pt.bad = bad;
+        };
+        const int n_parts = s->n_tri >= 60000u ? 4 : 1;
+        Part parts[4];
+        {
+            std::vector<std::thread> th;
+            for (int q = 1; q < n_parts; q++)
+                th.emplace_back(scan, (size_t)s->n_tri * q / n_parts, (size_t)s->n_tri * (q + 1) / n_parts, std::ref(parts[q]));
+            scan(0, (size_t)s->n_tri / n_parts, parts[0]);
+            for (std::thread &t : th) t.join();
+        }
+        float flo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, fhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        float worst = 0.0f;
+        for (int q = 0; q < n_parts; q++) {
+            for (int k = 0; k < 3; k++) { flo[k] = std::min(flo[k], parts[q].lo[k]); fhi[k] = std::max(fhi[k], parts[q].hi[k]); }
+            if (parts[q].bad) worst = 3.0e38f;
+        }
+        if (worst < 1e18f) {
+            if (s->n_tri) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)flo[k]); hi[k] = std::max(hi[k], (double)fhi[k]); }
+        } else {
+            for (uint32_t i = 0; i < s->n_tri; i++) {
+                const float *p = s->tri_p + 3 * (size_t)i, *a = s->tri_e1 + 3 * (size_t)i, *b = s->tri_e2 + 3 * (size_t)i;
+                grow(p[0], p[1], p[2]); grow(p[0] + a[0], p[1] + a[1], p[2] + a[2]); grow(p[0] + b[0], p[1] + b[1], p[2] + b[2]);
+            }
+        }
     }
     for (uint32_t i = 0; i < s->n_sph; i++) grow(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2]);
     grow(s->cam_pos[0], s->cam_pos[1], s->cam_pos[2]);
@@ -422,6 +604,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         S.theta = (nf && nf[0] == '1') ? 3.0e38f : 1.001f;
     }
 
+    STAGE("host bounds");
     // triangles
     float *d_p = nullptr, *d_e1 = nullptr, *d_e2 = nullptr;
     CHK(upload(h, s->tri_p, 3 * (size_t)s->n_tri, &d_p));
@@ -444,7 +627,9 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         const char *nc = knob("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
     }
+    STAGE("triangle upload + exact");
     CHK(build_bvh(h, ex, lo, hi, all_finite));
+    STAGE("hierarchy build");
     float *d_norm = nullptr, *d_uv = nullptr; int *d_tmat = nullptr;
     CHK(upload(h, s->tri_norm, 3 * (size_t)s->n_tri, &d_norm));
     CHK(upload(h, s->tri_uv, s->tri_uv ? 6 * (size_t)s->n_tri : 0, &d_uv, 6 * (size_t)std::max(1u, s->n_tri)));
@@ -500,6 +685,8 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     CHK(upload(h, lamp.data(), lamp.size(), &d_lamp)); CHK(upload(h, s->lamp_distance, s->n_lamp, &d_ld));
     S.lamp = d_lamp; S.lamp_dist = d_ld;
     HIPCHK(hipStreamSynchronize(h->stream));
+    pool_free(h->device, false, h->build_tmp);          // the hierarchy build has finished with its temporaries
+    h->build_tmp = nullptr;
     return HIPEXEC_OK;
 }
 
@@ -1263,10 +1450,10 @@ int import_rays(hipexec *h, const float *rays6, uint32_t n)
 // stream, events and counters of one lane
 int create_lane_resources(hipexec *h, uint32_t n_lamp)
 {
-    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    CHK(pool_stream(h->device, &h->own_stream));
     h->stream = h->own_stream;
     HIPCHK(hipEventCreate(&h->ev_begin)); HIPCHK(hipEventCreate(&h->ev_end));
-    HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    CHK(pool_stream(h->device, &h->side));
     for (hipEvent_t *e : {&h->ev_hits[0], &h->ev_hits[1], &h->ev_lit[0], &h->ev_lit[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (const char *e = knob("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
@@ -1284,14 +1471,14 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     if (const char *e = knob("HIPEXEC_BLOCK_TAIL")) h->block_tail = atoi(e);
     if (const char *e = knob("HIPEXEC_BLOCK64_BELOW")) h->block64_below = (uint32_t)strtoul(e, nullptr, 10);
     h->n_cnt32 = std::max(8u, n_lamp + 1u);
-    HIPCHK(hipMalloc((void **)&h->d_cnt32, h->n_cnt32 * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&h->d_cnt64, CNT64_WORDS * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **)&h->d_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t)));
-    HIPCHK(hipHostMalloc((void **)&h->h_lvl, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), hipHostMallocDefault));
+    CHK(pool_alloc(h->device, false, h->n_cnt32 * sizeof(uint32_t), (void **)&h->d_cnt32));
+    CHK(pool_alloc(h->device, false, CNT64_WORDS * sizeof(unsigned long long), (void **)&h->d_cnt64));
+    CHK(pool_alloc(h->device, false, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), (void **)&h->d_lvl));
+    CHK(pool_alloc(h->device, true, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), (void **)&h->h_lvl));
     if (const char *e = knob("HIPEXEC_PREDICT")) h->predict = atoi(e) != 0;
     if (const char *e = knob("HIPEXEC_PREDICT_SPOIL")) h->predict_spoil = atoi(e);   // test hook, see level_end
-    HIPCHK(hipHostMalloc((void **)&h->h_cnt32, h->n_cnt32 * sizeof(uint32_t), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_cnt64, CNT64_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    CHK(pool_alloc(h->device, true, h->n_cnt32 * sizeof(uint32_t), (void **)&h->h_cnt32));
+    CHK(pool_alloc(h->device, true, CNT64_WORDS * sizeof(unsigned long long), (void **)&h->h_cnt64));
     HIPCHK(hipMemsetAsync(h->d_cnt32, 0, h->n_cnt32 * sizeof(uint32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->d_cnt64, 0, CNT64_WORDS * sizeof(unsigned long long), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1338,8 +1525,11 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
     if (!h) return fail(HIPEXEC_E_NOMEM, "out of host memory");
     h->device = device;
     int rc = [&]() -> int {
+        StageTrace st; g_stage = &st;
+        struct Unset { ~Unset() { g_stage = nullptr; } } unset;
         CHK(static_scratch_init(device));
         CHK(create_lane_resources(h, scene->n_lamp));
+        STAGE("lane resources");
         if (const char *e = knob("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
         if (const char *e = knob("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
         if (const char *e = knob("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
@@ -1351,6 +1541,7 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
         if (const char *e = knob("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
         if (const char *e = knob("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
         CHK(build_scene(h, scene));
+        STAGE("rest of the scene");
         if (!h->bvh_default || !h->bvh_ok) CHK(ensure_scan_records(h));       // the scans are this executor's algorithm
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each
         // wave reads only the chunks it needs and the scalar path wins
@@ -1377,23 +1568,36 @@ void hipexec_destroy(hipexec_t *h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->side) { (void)hipStreamSynchronize(h->side); pool_stream_back(h->device, h->side); }
     for (hipEvent_t e : {h->ev_hits[0], h->ev_hits[1], h->ev_lit[0], h->ev_lit[1]}) if (e) (void)hipEventDestroy(e);
-    for (void *p : h->scene_allocs) (void)hipFree(p);
+    for (void *p : h->scene_allocs) pool_free(h->device, false, p);
+    pool_free(h->device, false, h->build_tmp);
     for (Buf *b : {&h->rayA, &h->rayB, &h->hit0, &h->hitN, &h->hitM, &h->local, &h->occl, &h->shadowq, &h->out_rgba, &h->out_ids,
                    &h->stage_in, &h->stage_out}) b->release();
-    if (h->d_cnt32) (void)hipFree(h->d_cnt32);
-    if (h->d_cnt64) (void)hipFree(h->d_cnt64);
-    if (h->d_lvl) (void)hipFree(h->d_lvl);
-    if (h->h_lvl) (void)hipHostFree(h->h_lvl);
-    if (h->h_cnt32) (void)hipHostFree(h->h_cnt32);
-    if (h->h_cnt64) (void)hipHostFree(h->h_cnt64);
+    pool_free(h->device, false, h->d_cnt32);
+    pool_free(h->device, false, h->d_cnt64);
+    pool_free(h->device, false, h->d_lvl);
+    pool_free(h->device, true, h->h_lvl);
+    pool_free(h->device, true, h->h_cnt32);
+    pool_free(h->device, true, h->h_cnt64);
     for (TimedLaunch &t : h->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); pool_stream_back(h->device, h->own_stream); }
     delete h;
+}
+
+int hipexec_trim(int device)
+{
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    if (device >= count) return fail(HIPEXEC_E_INVALID, "device %d out of range (%d devices)", device, count);
+    int cur = 0;
+    HIPCHK(hipGetDevice(&cur));
+    pool_trim(device);
+    HIPCHK(hipSetDevice(cur));
+    return HIPEXEC_OK;
 }
 
 int hipexec_set_stream(hipexec_t *h, void *stream)

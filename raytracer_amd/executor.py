@@ -178,6 +178,15 @@ class HipExecutor:
         return (colours, st) if want_stats else colours
 
 
+def trim(device: int = -1):
+    """Hands what the library's pool of device memory, pinned memory and streams holds for `device` (-1: all) back to the
+    driver (hipexec_destroy keeps them for the next executor)."""
+    lib = _abi.load_library()
+    rc = lib.hipexec_trim(int(device))
+    if rc != 0:
+        raise RuntimeError(f"hipexec_trim: {rc} ({lib.hipexec_last_error().decode()})")
+
+
 class FramesInFlight:
     """Throughput mode: `depth` executors of one scene, one lane each, take device-resident frames in turn.
 

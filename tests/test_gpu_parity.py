@@ -516,3 +516,27 @@ def test_ambient_occlusion_mode_matches_its_cpu_definition(name, depth):
             ex.render(W, H, mode=CPU, max_depth=depth, ao=True, algo="scan")
         again = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)         # the refused call leaves the executor usable
         assert np.array_equal(again["rgb"].view(np.int32), back["rgb"].view(np.int32))
+
+
+def test_executors_made_from_pooled_memory_render_the_same_frames():
+    """hipexec_destroy hands device memory, pinned memory and streams to a pool that serves the next hipexec_create (the
+    reference makes an executor per frame, ray_tracer_cl.cpp:14).  Executors of different scenes made one after the
+    other therefore get each other's blocks with their old contents: every frame must still be the oracle's, for both
+    algorithms, and hipexec_trim must leave the library usable."""
+    from raytracer_amd import executor
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    W, H = 64, 48
+    scenes = [scenegen.small_variant(n).to_flat() for n in ("mirror", "soup", "c5", "mirror", "c2")]
+    refs = [Oracle(fs).render(W, H, mode=CPU, max_depth=2, tone=0, n_threads=8) for fs in scenes]
+    for round_ in range(3):
+        for fs, ref in zip(scenes, refs):
+            with HipExecutor(fs, device=0) as ex:                      # created, used once, destroyed
+                for algo in ("bvh", "scan") if round_ == 1 else ("bvh",):
+                    got = ex.render(W, H, mode=CPU, max_depth=2, tone=False, algo=algo)
+                    assert np.array_equal(got["ids"], ref["ids"]), (round_, algo)
+                    assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4, (round_, algo)
+                    assert got["stats"].rays == ref["stats"].rays
+        if round_ == 1:
+            executor.trim()                                            # everything cached goes back to the driver
+    executor.trim(0)

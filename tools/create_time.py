@@ -9,6 +9,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 fs = {"c2": scenegen.scene_c2, "c5": scenegen.scene_c5, "c4": scenegen.scene_c4, "c1": scenegen.scene_c1}[wl]().to_flat()
 W, H = 800, 600
 out = np.zeros((H, W, 3), np.float32)
+os.environ["HIPEXEC_TRACE_CREATE"] = os.environ.get("HIPEXEC_TRACE_CREATE", "0")
 for i in range(5):
     t0 = time.perf_counter()
     ex = HipExecutor(fs, device=0)
