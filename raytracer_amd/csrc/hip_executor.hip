@@ -472,7 +472,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
 
     // temporaries: one block, carved up, released at the end
     unsigned long long *keys_a = nullptr, *keys_b = nullptr;
-    uint32_t *child = nullptr, *parent = nullptr, *range = nullptr, *arrived = nullptr;
+    uint32_t *child = nullptr, *parent = nullptr, *range = nullptr, *arrived = nullptr, *top_list = nullptr;
     float4 *box_lo = nullptr, *box_hi = nullptr, *nrm_lo = nullptr, *nrm_hi = nullptr;
     void *sort_tmp = nullptr;
     size_t tmp_bytes = 0;
@@ -480,16 +480,18 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     char *block = nullptr;
     size_t used = 0;
     auto carve = [&](size_t bytes) -> void * { void *p = block + used; used += (bytes + 255) / 256 * 256; return p; };
-    const size_t total = 2 * (8 * (size_t)n + 256) + 3 * (8 * (size_t)n + 256) + (4 * (size_t)n + 256) + 4 * (32 * (size_t)n + 256) + tmp_bytes + 256;
+    const size_t total = 2 * (8 * (size_t)n + 256) + 3 * (8 * (size_t)n + 256) + 2 * (4 * (size_t)n + 512) + 4 * (32 * (size_t)n + 256) + tmp_bytes + 256;
     CHK(pool_alloc(h->device, false, total, (void **)&block));
     int rc = [&]() -> int {
         keys_a = (unsigned long long *)carve(8 * (size_t)n); keys_b = (unsigned long long *)carve(8 * (size_t)n);
         child = (uint32_t *)carve(8 * (size_t)n); parent = (uint32_t *)carve(8 * (size_t)n); range = (uint32_t *)carve(8 * (size_t)n);
-        arrived = (uint32_t *)carve(4 * (size_t)n);
+        arrived = (uint32_t *)carve(4 * (size_t)n + 4);          // + the count of top_list
+        top_list = (uint32_t *)carve(4 * (size_t)n);
         box_lo = (float4 *)carve(32 * (size_t)n); box_hi = (float4 *)carve(32 * (size_t)n);
         nrm_lo = (float4 *)carve(32 * (size_t)n); nrm_hi = (float4 *)carve(32 * (size_t)n);
         sort_tmp = carve(tmp_bytes);
-        HIPCHK(hipMemsetAsync(arrived, 0, 4 * (size_t)n, h->stream));
+        HIPCHK(hipMemsetAsync(arrived, 0, 4 * (size_t)n + 4, h->stream));
+        uint32_t *top_count = arrived + n;
         f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
         float ext[3];
         for (int k = 0; k < 3; k++) ext[k] = (float)(hi[k] - lo[k]);
@@ -503,11 +505,11 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi, nrm_lo, nrm_hi);
         HIPCHK(hipGetLastError());
         if (n >= 2) {
-            hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range);
+            hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range, top_list, top_count);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_bvh_refit, dim3((n + REFIT_BLOCK - 1) / REFIT_BLOCK), dim3(REFIT_BLOCK), 0, h->stream, n, child, parent, range, arrived,
                                box_lo, box_hi, nrm_lo, nrm_hi);
-            hipLaunchKernelGGL(k_bvh_refit_top, dim3(1), dim3(1024), 0, h->stream, n, child, range, arrived, box_lo, box_hi, nrm_lo, nrm_hi);
+            hipLaunchKernelGGL(k_bvh_refit_top, dim3(1), dim3(1024), 0, h->stream, n, child, range, top_list, top_count, arrived, box_lo, box_hi, nrm_lo, nrm_hi);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, child, range, box_lo, box_hi, nrm_lo, nrm_hi, nodes);
             HIPCHK(hipGetLastError());

@@ -123,8 +123,12 @@ DEV int bvh_delta(const unsigned long long *keys, int n, int i, int j) {
     return __clzll((long long)(keys[i] ^ keys[j]));
 }
 
+constexpr uint32_t REFIT_BLOCK = 256;     // leaves per block of k_bvh_refit
+
+// (also lists the inner nodes whose leaves reach across blocks of k_bvh_refit: top_list[0 .. *top_count), any order)
 __global__ void k_bvh_split(uint32_t n, const unsigned long long *__restrict__ keys, uint32_t *__restrict__ child,
-                            uint32_t *__restrict__ parent, uint32_t *__restrict__ range)
+                            uint32_t *__restrict__ parent, uint32_t *__restrict__ range, uint32_t *__restrict__ top_list,
+                            uint32_t *__restrict__ top_count)
 {
     int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     int N = (int)n;
@@ -151,6 +155,7 @@ __global__ void k_bvh_split(uint32_t n, const unsigned long long *__restrict__ k
     parent[left] = (uint32_t)i; parent[right] = (uint32_t)i;
     range[2 * i] = (uint32_t)first; range[2 * i + 1] = (uint32_t)last;
     if (i == 0) parent[0] = 0xffffffffu;
+    if ((uint32_t)first / REFIT_BLOCK != (uint32_t)last / REFIT_BLOCK) top_list[atomicAdd(top_count, 1u)] = (uint32_t)i;
 }
 
 // Boxes (and normal boxes) bottom-up in two launches.  k_bvh_refit: a block owns REFIT_BLOCK consecutive leaves and computes
@@ -160,8 +165,6 @@ __global__ void k_bvh_split(uint32_t n, const unsigned long long *__restrict__ k
 // visible) and relaxes them round by round with barriers.  (One launch with device-scope fences at those nodes took
 // 0.34-0.66 ms for 100 k triangles: on this chip a device-scope release writes back an XCD's L2, and the path to the root is a
 // chain of them.)
-constexpr uint32_t REFIT_BLOCK = 256;
-
 DEV void bvh_refit_node(uint32_t cur, const uint32_t *child, float4 *box_lo, float4 *box_hi, float4 *nrm_lo, float4 *nrm_hi) {
     uint32_t a = child[2 * cur], b = child[2 * cur + 1];
     float4 la = box_lo[a], ha = box_hi[a], lb = box_lo[b], hb = box_hi[b];
@@ -191,33 +194,20 @@ __global__ __launch_bounds__(REFIT_BLOCK) void k_bvh_refit(uint32_t n, const uin
     }
 }
 
-// `done` = the array `arrived` of the first launch, reused: a node of this launch is done when its entry is 3
-constexpr uint32_t REFIT_TOP_LIST = 12288;
-
+// `done` = the array `arrived` of the first launch, reused: a node of this launch is done when its entry is 3.  One block;
+// a round computes every listed node whose children are ready, rounds until none is left (as many as the listed nodes are deep).
 __global__ __launch_bounds__(1024) void k_bvh_refit_top(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ range,
+                                                          const uint32_t *__restrict__ top_list, const uint32_t *__restrict__ top_count,
                                                           uint32_t *done, float4 *box_lo, float4 *box_hi, float4 *nrm_lo, float4 *nrm_hi)
 {
-    __shared__ uint32_t list[REFIT_TOP_LIST];
-    __shared__ uint32_t n_list, pending;
+    __shared__ uint32_t pending;
     if (n < 2) return;
-    const uint32_t n_inner = n - 1u;
-    if (threadIdx.x == 0) n_list = 0u;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_inner; i += blockDim.x)
-        if (!bvh_refit_local(i, range)) {
-            uint32_t pos = atomicAdd(&n_list, 1u);
-            if (pos < REFIT_TOP_LIST) list[pos] = i;
-        }
-    __syncthreads();
-    const uint32_t total = n_list;
-    const bool listed = total <= REFIT_TOP_LIST;                 // else every round goes through all inner nodes (slow, correct)
-    const uint32_t count = listed ? total : n_inner;
+    const uint32_t n_inner = n - 1u, count = *top_count;
     for (;;) {
         if (threadIdx.x == 0) pending = 0u;
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < count; j += blockDim.x) {
-            const uint32_t i = listed ? list[j] : j;
-            if (!listed && bvh_refit_local(i, range)) continue;
+            const uint32_t i = top_list[j];
             if (done[i] == 3u) continue;
             const uint32_t a = child[2 * i], b = child[2 * i + 1];
             const bool ra = a >= n_inner || bvh_refit_local(a, range) || done[a] == 3u;
