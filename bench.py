@@ -372,7 +372,9 @@ def main(argv=None):
         ref_flops = [scan_equiv_flops(st, k, fs.n_sph) for k in range(3)]
     # One untimed frame with every kernel class timed picks the dominant class; the timed steps then bracket only that
     # class's launches with events (every timed launch costs two event records on its stream).
-    for _ in range(args.warmup):
+    # every executor of the pipeline renders once before anything is timed (its buffers and its remembered queue sizes
+    # belong to it): the W warm-up steps, and more where W is smaller than the number of executors
+    for _ in range(max(args.warmup, in_flight)):
         step(False)
     step(True)
     probe_ms = [float(st.kernel_ms[k]) for k in range(4)]
