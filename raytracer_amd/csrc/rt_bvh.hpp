@@ -14,13 +14,17 @@
 //   k_bvh_leaves  triangle records gathered into key order, leaf boxes
 //   k_bvh_split   binary radix tree over the sorted keys, one thread per internal node
 //                 (longest-common-prefix construction; every node knows its key range)
-//   k_bvh_refit   boxes bottom-up, second thread to arrive at a node computes it
+//   k_bvh_refit   boxes bottom-up inside blocks of 256 leaves, second thread to arrive at a node computes it;
+//   k_bvh_refit_top  the nodes that reach across those blocks, one block, round by round
 //   k_bvh_emit    4-wide traversal nodes: the boxes of a node's grandchildren and the node's normal
 //                 cone in one 144-byte record, so a ray makes half the dependent fetches of a binary
 //                 walk; subtrees with at most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
-// Frame kernels: k_raygen, k_bvh_closest_p (lanes take the next ray of their block when theirs is
-// decided), k_bvh_shadow (shadow rays compacted per block in LDS); k_bvh_closest and k_bvh_anyhit
-// are the plain one-ray-per-lane forms used by the batch entry points and for A/B runs.
+// Frame kernels: k_bvh_closest_pk (makes the camera rays and walks the 64 of a wave as one packet), k_bvh_closest (bounce
+// rays and batch calls, one ray per lane; k_bvh_closest_p is its form whose lanes take a new ray when theirs is decided,
+// kept for A/B runs), k_bvh_shadow_direct (a lane keeps its sample and traces its shadow rays lamp after lamp, then
+// shades the sample; k_bvh_shadow is the older form with a per-block list of (sample, lamp) pairs), k_bvh_tail (follows
+// the rays of a small queue to the end of their paths), k_bvh_anyhit (batch calls).  The per-lane kernels are templates
+// on the block size: launches of few rays use one-wave blocks.
 #pragma once
 #include "rt_kernels.hpp"
 
