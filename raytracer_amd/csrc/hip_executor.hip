@@ -316,6 +316,7 @@ struct hipexec {
     uint32_t lamp_words = 1;
     std::vector<void *> scene_allocs;         // chunks of the scene arena
     char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    hipStream_t upload_stream = nullptr;      // stream of upload() while it is not the executor's (scene set-up: beside the hierarchy build)
     void *build_tmp = nullptr;                // temporaries of the hierarchy build, until the build has been waited for
     float *d_tri_p = nullptr, *d_tri_e1 = nullptr, *d_tri_e2 = nullptr;   // the caller's triangle arrays on the device (set-up kernels read them)
     std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
@@ -419,8 +420,9 @@ int upload(hipexec *h, const T *src, size_t count, T **dst, size_t min_count = 1
     void *p = nullptr;
     CHK(scene_alloc(h, n * sizeof(T), &p));
     size_t copied = (count && src) ? count : 0;
-    if (copied) HIPCHK(hipMemcpyAsync(p, src, copied * sizeof(T), hipMemcpyHostToDevice, h->stream));
-    if (copied < n) HIPCHK(hipMemsetAsync(static_cast<char *>(p) + copied * sizeof(T), 0, (n - copied) * sizeof(T), h->stream));
+    hipStream_t st = h->upload_stream ? h->upload_stream : h->stream;
+    if (copied) HIPCHK(hipMemcpyAsync(p, src, copied * sizeof(T), hipMemcpyHostToDevice, st));
+    if (copied < n) HIPCHK(hipMemsetAsync(static_cast<char *>(p) + copied * sizeof(T), 0, (n - copied) * sizeof(T), st));
     *dst = reinterpret_cast<T *>(p);
     return HIPEXEC_OK;
 }
@@ -632,6 +634,9 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     STAGE("triangle upload + exact");
     CHK(build_bvh(h, ex, lo, hi, all_finite));
     STAGE("hierarchy build");
+    // what the build does not read goes up on the side stream while the build's kernels run
+    h->upload_stream = h->side;
+    struct Restore { hipexec *h; ~Restore() { h->upload_stream = nullptr; } } restore{h};
     float *d_norm = nullptr, *d_uv = nullptr; int *d_tmat = nullptr;
     CHK(upload(h, s->tri_norm, 3 * (size_t)s->n_tri, &d_norm));
     CHK(upload(h, s->tri_uv, s->tri_uv ? 6 * (size_t)s->n_tri : 0, &d_uv, 6 * (size_t)std::max(1u, s->n_tri)));
@@ -686,6 +691,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     float4 *d_lamp = nullptr; float *d_ld = nullptr;
     CHK(upload(h, lamp.data(), lamp.size(), &d_lamp)); CHK(upload(h, s->lamp_distance, s->n_lamp, &d_ld));
     S.lamp = d_lamp; S.lamp_dist = d_ld;
+    HIPCHK(hipStreamSynchronize(h->side));
     HIPCHK(hipStreamSynchronize(h->stream));
     pool_free(h->device, false, h->build_tmp);          // the hierarchy build has finished with its temporaries
     h->build_tmp = nullptr;
