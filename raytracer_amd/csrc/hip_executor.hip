@@ -467,7 +467,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 3));      // + one record: a one-triangle leaf is fetched as two
     CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
-    CHK(upload<float4>(h, nullptr, 0, &nodes, 9 * (size_t)n + 1));
+    CHK(upload<float4>(h, nullptr, 0, &nodes, BVH_NODE_F4 * (size_t)n + 1));
     B.tris = tris; B.ids = ids; B.nodes = nodes;
     if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
     B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;

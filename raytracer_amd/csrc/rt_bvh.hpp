@@ -17,7 +17,7 @@
 //   k_bvh_refit   boxes bottom-up inside blocks of 256 leaves, second thread to arrive at a node computes it;
 //   k_bvh_refit_top  the nodes that reach across those blocks, one block, round by round
 //   k_bvh_emit    4-wide traversal nodes: the boxes of a node's grandchildren and the node's normal
-//                 cone in one 144-byte record, so a ray makes half the dependent fetches of a binary
+//                 cone in one 128-byte record (a cache line), so a ray makes half the dependent fetches of a binary
 //                 walk; subtrees with at most BVH_LEAF_MAX triangles become leaves (contiguous in key order)
 // Frame kernels: k_bvh_closest_pk (makes the camera rays and walks the 64 of a wave as one packet), k_bvh_closest (bounce
 // rays and batch calls, one ray per lane; k_bvh_closest_p is its form whose lanes take a new ray when theirs is decided,
@@ -47,10 +47,13 @@ constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
 constexpr float BVH_TIGHT = 4.0e-6f;
 constexpr float BVH_TIGHT_MIN = 500.0f;         // tight bound used only if (|cos| * sine) >= BVH_TIGHT * BVH_TIGHT_MIN = 2e-3
+constexpr int BVH_NODE_F4 = 8;                  // float4 per inner-node record: 128 bytes, one cache line
 
 struct DBvh {
-    const float4 *nodes;    // 9 float4 per internal node: 4 x {lo, A}, 4 x {hi, ref} of up to four grandchildren (unused
-                            // slots have ref BVH_NONE), then the cone {axis * k, sine * k} of the node's own triangles
+    const float4 *nodes;    // BVH_NODE_F4 float4 per internal node, 128-byte aligned: 4 x {lo, w}, 4 x {hi, ref} of up to four
+                            // grandchildren (unused slots have ref BVH_NONE).  The four w words carry what belongs to the
+                            // node as a whole: w0 = two bfloat16 {A (high half), sine * k (low half)}, both rounded up,
+                            // w1..w3 = axis * k of the cone of the node's own triangles
     const float4 *tris;     // 3 float4 per triangle in key order: {p, c21.x} {e1, c21.y} {e2, c21.z}
     const uint32_t *ids;    // triangle index of the k-th record
     uint32_t root;          // reference of the root (BVH_NONE for an empty scene)
@@ -254,9 +257,15 @@ DEV float4 bvh_cone(float4 nl, float4 nh) {
     return make_float4(a.x * (ca * k), a.y * (ca * k), a.z * (ca * k), sa * k);
 }
 
+// Upper 16 bits of the smallest bfloat16 that is >= x, for finite x >= 0 (the largest finite bfloat16 beyond that).
+DEV uint32_t bf16_up(float x) {
+    uint32_t u = (__float_as_uint(x) + 0xffffu) >> 16;
+    return u > 0x7f7fu ? 0x7f7fu : u;
+}
+
 // A node lists up to four descendants (its children, the larger ones opened once more) and carries one
-// cone, that of all its triangles.  (A cone per slot prunes a little more but the larger record costs more
-// than that saves.)
+// cone and one A, those of all its triangles.  (A cone per slot prunes a little more but the larger record costs
+// more than that saves; a ninth float4 for the cone, with A per slot, made every node visit touch two cache lines.)
 __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const uint32_t *__restrict__ range,
                             const float4 *__restrict__ box_lo, const float4 *__restrict__ box_hi,
                             const float4 *__restrict__ nrm_lo, const float4 *__restrict__ nrm_hi, float4 *__restrict__ nodes)
@@ -280,13 +289,17 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
         slot[pick] = child[2 * c];
         slot[ns++] = child[2 * c + 1];
     }
-    float4 *N = nodes + 9 * (size_t)i;
+    // what belongs to the node as a whole travels in the w words of the four lo entries, so that the record is one
+    // 128-byte cache line: A of all the node's triangles (the largest of its slots' values) and the cone
+    const float4 cone = bvh_cone(nrm_lo[i], nrm_hi[i]);
+    const float w[4] = {__uint_as_float((bf16_up(box_lo[i].w) << 16) | bf16_up(cone.w)), cone.x, cone.y, cone.z};
+    float4 *N = nodes + BVH_NODE_F4 * (size_t)i;
     for (int k = 0; k < 4; k++) {
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = make_float4(0.f, 0.f, 0.f, __uint_as_float(BVH_NONE));   // unused slot
         if (k < ns) { lo = box_lo[slot[k]]; hi = box_hi[slot[k]]; hi.w = __uint_as_float(bvh_ref_of(slot[k], n, range)); }
+        lo.w = w[k];
         N[k] = lo; N[4 + k] = hi;
     }
-    N[8] = bvh_cone(nrm_lo[i], nrm_hi[i]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -328,12 +341,12 @@ DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
 }
 
 // entry parameter of the enlarged box if the half-line t >= 0 may reach it at t <= limit;
-// `rg` = 1/g for the cone the box belongs to, or 0 where the tight form does not apply
-DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float rg, float limit, float &tnear) {
+// `ad` = A * |d| of the node the box belongs to, `rg` = 1/g for its cone, or 0 where the tight form does not apply
+DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float ad, float rg, float limit, float &tnear) {
     float lx = lo.x - r.o.x, ly = lo.y - r.o.y, lz = lo.z - r.o.z;
     float hx = hi.x - r.o.x, hy = hi.y - r.o.y, hz = hi.z - r.o.z;
     float qb = (fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy))) + fmaxf(fabsf(lz), fabsf(hz));
-    float in = (lo.w * r.dlen) * qb;
+    float in = ad * qb;
     if (rg > 0.0f) in = fminf(in, qb * rg);
     in += r.E;
     float t1x = (lx - in) * r.inv.x, t2x = (hx + in) * r.inv.x;
@@ -411,12 +424,13 @@ DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__
     float4 lo[4], hi[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { lo[k] = N[k]; hi[k] = N[4 + k]; }
-    float4 cone = N[8];
-    float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
+    const uint32_t w0 = __float_as_uint(lo[0].w);
+    const float ad = __uint_as_float(w0 & 0xffff0000u) * r.dlen;
+    float g = fabsf(fmaf(lo[3].w, r.dhat.z, fmaf(lo[2].w, r.dhat.y, lo[1].w * r.dhat.x))) - __uint_as_float(w0 << 16);
     float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
     float tk[4]; bool hk[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
+    for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], ad, rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
     if (!SORT) {
         // Any-hit rays: the answer does not depend on the order of the walk, and ordering the slots by entry distance
         // (five compare-exchanges) costs more than it finds occluders sooner (measured: C5 -8 %, C2 -2.5 % without it).
@@ -503,10 +517,10 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             const bool uniform = nodes_sc != nullptr && __ballot(at_inner && node == lead_node) == m_inner;
             if (uniform) {
                 const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)lead_node);
-                if (at_inner) { n_nodes++; bvh_inner_step<true, !ANY, BS>(B, r, nodes_sc + 9 * (size_t)un, limit, stk, node, sp, overflow); }
+                if (at_inner) { n_nodes++; bvh_inner_step<true, !ANY, BS>(B, r, nodes_sc + BVH_NODE_F4 * (size_t)un, limit, stk, node, sp, overflow); }
             } else if (at_inner) {
                 n_nodes++;
-                bvh_inner_step<false, !ANY, BS>(B, r, B.nodes + 9 * (size_t)node, limit, stk, node, sp, overflow);
+                bvh_inner_step<false, !ANY, BS>(B, r, B.nodes + BVH_NODE_F4 * (size_t)node, limit, stk, node, sp, overflow);
             }
         } else if (at_leaf) {
             uint32_t first = node & 0x0fffffffu, cnt = (node >> 28) & 7u;
@@ -617,22 +631,23 @@ DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float 
             if (ANY) alive &= ~__ballot(found != 0u);
             node = BVH_NONE;
         } else {
-            const float4 *N = NB + 9 * (size_t)node;
+            const float4 *N = NB + BVH_NODE_F4 * (size_t)node;
             float4 lo[4], hi[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) { lo[k] = N[k]; hi[k] = N[4 + k]; }
-            float4 cone = N[8];
             float tk[4]; bool hk[4] = {false, false, false, false};
             if (mine) {
                 n_nodes++;
-                float g = fabsf(fmaf(cone.z, r.dhat.z, fmaf(cone.y, r.dhat.y, cone.x * r.dhat.x))) - cone.w;
+                const uint32_t w0 = __float_as_uint(lo[0].w);
+                const float ad = __uint_as_float(w0 & 0xffff0000u) * r.dlen;
+                float g = fabsf(fmaf(lo[3].w, r.dhat.z, fmaf(lo[2].w, r.dhat.y, lo[1].w * r.dhat.x))) - __uint_as_float(w0 << 16);
                 float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
                 // The record sits in scalar registers, so an unused slot (29 % of them with two triangles per leaf) is
                 // skipped by a scalar branch.  (The same branch in the uniform steps of the shadow rays: C5 +2 %.)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     tk[k] = 0.0f;
-                    if (__float_as_uint(hi[k].w) != BVH_NONE) hk[k] = bvh_box(r, lo[k], hi[k], rg, limit, tk[k]);
+                    if (__float_as_uint(hi[k].w) != BVH_NONE) hk[k] = bvh_box(r, lo[k], hi[k], ad, rg, limit, tk[k]);
                 }
             }
             // the slot that the first interested lane would enter first is walked next, the others are pushed
