@@ -22,6 +22,7 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <limits>
 #include <vector>
 
 #include "hip_executor.h"
@@ -463,6 +464,12 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     B.stack_limit = BVH_STACK;
     if (const char *e = knob("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
     B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
+    // clamp of the slab test's reciprocals (tray_make): at least 1e12 * size^2, from the shortest direction that can pass
+    // the exact tests' |det| > 1e-4 with edges of at most 2 sqrt(3) times the scene's size; none where that leaves the float range
+    {
+        const double want = std::max(1.0e30, 1.0e12 * (double)B.scene_mag * (double)B.scene_mag);
+        B.inv_clamp = want < 3.0e38 ? (float)want : std::numeric_limits<float>::infinity();
+    }
     h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 3));      // + one record: a one-triangle leaf is fetched as two

@@ -50,15 +50,17 @@ constexpr float BVH_TIGHT_MIN = 500.0f;         // tight bound used only if (|co
 constexpr int BVH_NODE_F4 = 8;                  // float4 per inner-node record: 128 bytes, one cache line
 
 struct DBvh {
-    const float4 *nodes;    // BVH_NODE_F4 float4 per internal node, 128-byte aligned: 4 x {lo, w}, 4 x {hi, ref} of up to four
-                            // grandchildren (unused slots have ref BVH_NONE).  The four w words carry what belongs to the
-                            // node as a whole: w0 = two bfloat16 {A (high half), sine * k (low half)}, both rounded up,
-                            // w1..w3 = axis * k of the cone of the node's own triangles
+    const float4 *nodes;    // BVH_NODE_F4 float4 per internal node, 128-byte aligned: 4 x {centre, w}, 4 x {half extent, ref}
+                            // of the boxes of up to four grandchildren (unused slots have ref BVH_NONE; centre +- half
+                            // extent contains the box).  The four w words carry what belongs to the node as a whole:
+                            // w0 = two bfloat16 {A (high half), sine * k (low half)}, both rounded up, w1..w3 = axis * k
+                            // of the cone of the node's own triangles
     const float4 *tris;     // 3 float4 per triangle in key order: {p, c21.x} {e1, c21.y} {e2, c21.z}
     const uint32_t *ids;    // triangle index of the k-th record
     uint32_t root;          // reference of the root (BVH_NONE for an empty scene)
     uint32_t n;             // triangles
     float scene_mag;        // bound on |coordinate| of any box corner
+    float inv_clamp;        // largest |1 / direction component| the slab test uses (see tray_make)
     int stack_limit;        // usable entries of the traversal stack, <= BVH_STACK (lowered only to test the overflow path)
 };
 
@@ -263,6 +265,9 @@ DEV uint32_t bf16_up(float x) {
     return u > 0x7f7fu ? 0x7f7fu : u;
 }
 
+// next float above a half extent h >= 0 (covers the rounding of the subtraction that made it); 0 stays 0
+DEV float half_up(float h) { return h > 0.0f ? __uint_as_float(__float_as_uint(h) + 1u) : 0.0f; }
+
 // A node lists up to four descendants (its children, the larger ones opened once more) and carries one
 // cone and one A, those of all its triangles.  (A cone per slot prunes a little more but the larger record costs
 // more than that saves; a ninth float4 for the cone, with A per slot, made every node visit touch two cache lines.)
@@ -296,7 +301,13 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
     float4 *N = nodes + BVH_NODE_F4 * (size_t)i;
     for (int k = 0; k < 4; k++) {
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = make_float4(0.f, 0.f, 0.f, __uint_as_float(BVH_NONE));   // unused slot
-        if (k < ns) { lo = box_lo[slot[k]]; hi = box_hi[slot[k]]; hi.w = __uint_as_float(bvh_ref_of(slot[k], n, range)); }
+        if (k < ns) {
+            // centre and half extent, the half extent rounded up so that centre +- half extent contains the box
+            const float4 bl = box_lo[slot[k]], bh = box_hi[slot[k]];
+            lo = make_float4(0.5f * (bl.x + bh.x), 0.5f * (bl.y + bh.y), 0.5f * (bl.z + bh.z), 0.f);
+            hi = make_float4(half_up(fmaxf(bh.x - lo.x, lo.x - bl.x)), half_up(fmaxf(bh.y - lo.y, lo.y - bl.y)),
+                             half_up(fmaxf(bh.z - lo.z, lo.z - bl.z)), __uint_as_float(bvh_ref_of(slot[k], n, range)));
+        }
         lo.w = w[k];
         N[k] = lo; N[4 + k] = hi;
     }
@@ -331,7 +342,14 @@ struct TRay { f3 o, inv, dhat; float dlen, E; };
 DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     TRay r;
     r.o = o;
-    r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // A direction component of (nearly) zero would make its slab terms infinite and their differences NaN.  The
+    // reciprocals are clamped to +-inv_clamp instead: an origin outside such a slab still gives an empty interval
+    // (of the order of inv_clamp * distance, far beyond any ray parameter), an origin inside one that reaches past every
+    // parameter at which a hit can be accepted.  For that the clamp must exceed 6e6 / |d| for the shortest direction
+    // that can still pass the |det| thresholds, |d| >= 1e-4 / (|e1||e2|): build_bvh sets it from the scene's size
+    // (infinite, i.e. no clamp, for astronomically large scenes, whose axis-parallel rays then lose that axis' culling).
+    const float ic = B.inv_clamp;
+    r.inv = mk(fminf(fmaxf(1.0f / d.x, -ic), ic), fminf(fmaxf(1.0f / d.y, -ic), ic), fminf(fmaxf(1.0f / d.z, -ic), ic));
     r.dlen = sqrtf(dot(d, d));
     float il = 1.0f / r.dlen;
     r.dhat = d * il;
@@ -340,20 +358,20 @@ DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     return r;
 }
 
-// entry parameter of the enlarged box if the half-line t >= 0 may reach it at t <= limit;
-// `ad` = A * |d| of the node the box belongs to, `rg` = 1/g for its cone, or 0 where the tight form does not apply
-DEV bool bvh_box(const TRay &r, float4 lo, float4 hi, float ad, float rg, float limit, float &tnear) {
-    float lx = lo.x - r.o.x, ly = lo.y - r.o.y, lz = lo.z - r.o.z;
-    float hx = hi.x - r.o.x, hy = hi.y - r.o.y, hz = hi.z - r.o.z;
-    float qb = (fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy))) + fmaxf(fabsf(lz), fabsf(hz));
-    float in = ad * qb;
-    if (rg > 0.0f) in = fminf(in, qb * rg);
-    in += r.E;
-    float t1x = (lx - in) * r.inv.x, t2x = (hx + in) * r.inv.x;
-    float t1y = (ly - in) * r.inv.y, t2y = (hy + in) * r.inv.y;
-    float t1z = (lz - in) * r.inv.z, t2z = (hz + in) * r.inv.z;
-    float tmin = max3f(fminf(t1x, t2x), fminf(t1y, t2y), fminf(t1z, t2z));
-    float tmax = min3f(fmaxf(t1x, t2x), fmaxf(t1y, t2y), fmaxf(t1z, t2z));
+// entry parameter of the enlarged box if the half-line t >= 0 may reach it at t <= limit; the box is centre `cw` +-
+// half extent `hr`; `ad` = A * |d| of the node the box belongs to, `rg` = 1/g for its cone, or +inf where the tight form
+// does not apply.  With the box as centre and half extent the two faces of an axis are tc -+ th, th >= 0, already in
+// order: no min/max per axis.  A NaN (inf - inf or 0 * inf, unclamped reciprocals only) drops out of the min3 / max3,
+// which can only widen the interval.
+DEV bool bvh_box(const TRay &r, float4 cw, float4 hr, float ad, float rg, float limit, float &tnear) {
+    float cx = cw.x - r.o.x, cy = cw.y - r.o.y, cz = cw.z - r.o.z;
+    float qb = ((fabsf(cx) + hr.x) + (fabsf(cy) + hr.y)) + (fabsf(cz) + hr.z);     // L1 distance of the farthest corner
+    float in = fminf(ad * qb, qb * rg) + r.E;
+    float hx = hr.x + in, hy = hr.y + in, hz = hr.z + in;
+    float tcx = cx * r.inv.x, tcy = cy * r.inv.y, tcz = cz * r.inv.z;
+    float ax = fabsf(r.inv.x), ay = fabsf(r.inv.y), az = fabsf(r.inv.z);
+    float tmin = max3f(fmaf(-hx, ax, tcx), fmaf(-hy, ay, tcy), fmaf(-hz, az, tcz));
+    float tmax = min3f(fmaf(hx, ax, tcx), fmaf(hy, ay, tcy), fmaf(hz, az, tcz));
     tnear = tmin;
     return (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= limit);
 }
@@ -427,7 +445,7 @@ DEV void bvh_inner_step(const DBvh &B, const TRay &r, const float4 *__restrict__
     const uint32_t w0 = __float_as_uint(lo[0].w);
     const float ad = __uint_as_float(w0 & 0xffff0000u) * r.dlen;
     float g = fabsf(fmaf(lo[3].w, r.dhat.z, fmaf(lo[2].w, r.dhat.y, lo[1].w * r.dhat.x))) - __uint_as_float(w0 << 16);
-    float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
+    float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : __builtin_inff();
     float tk[4]; bool hk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) hk[k] = bvh_box(r, lo[k], hi[k], ad, rg, limit, tk[k]) && __float_as_uint(hi[k].w) != BVH_NONE;
@@ -641,7 +659,7 @@ DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float 
                 const uint32_t w0 = __float_as_uint(lo[0].w);
                 const float ad = __uint_as_float(w0 & 0xffff0000u) * r.dlen;
                 float g = fabsf(fmaf(lo[3].w, r.dhat.z, fmaf(lo[2].w, r.dhat.y, lo[1].w * r.dhat.x))) - __uint_as_float(w0 << 16);
-                float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : 0.0f;
+                float rg = (g >= BVH_TIGHT_MIN) ? __builtin_amdgcn_rcpf(g) : __builtin_inff();
                 // The record sits in scalar registers, so an unused slot (29 % of them with two triangles per leaf) is
                 // skipped by a scalar branch.  (The same branch in the uniform steps of the shadow rays: C5 +2 %.)
 #pragma unroll
