@@ -34,10 +34,10 @@ constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 2;
 #ifndef RT_BVH_STACK
-#define RT_BVH_STACK 24
+#define RT_BVH_STACK 22
 #endif
 #ifndef RT_CLOSEST_WAVES
-#define RT_CLOSEST_WAVES 6
+#define RT_CLOSEST_WAVES 7
 #endif
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 5
