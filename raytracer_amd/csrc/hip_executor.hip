@@ -366,7 +366,7 @@ struct hipexec {
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
-    uint32_t shadow_waves6_from = 8u;         // HIPEXEC_SHADOW_WAVES6_FROM: lamps from which the shadow kernel compiled for 6 waves per SIMD is used
+    uint32_t shadow_waves6_from = 2u;         // HIPEXEC_SHADOW_WAVES6_FROM: lamps from which the shadow kernel compiled for 6 waves per SIMD is used
     uint32_t simple_from = 0u;                // HIPEXEC_SIMPLE_FROM: closest-hit launches of at least this many rays take one ray per lane
                                               // (k_bvh_closest); smaller ones the kernel whose lanes fetch a new ray when theirs is decided
     bool shadow_direct = true;                // HIPEXEC_SHADOW_DIRECT=0: shadow rays through the block's list in LDS (k_bvh_shadow)

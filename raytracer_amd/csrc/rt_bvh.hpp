@@ -348,10 +348,13 @@ DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     // parameter at which a hit can be accepted.  For that the clamp must exceed 6e6 / |d| for the shortest direction
     // that can still pass the |det| thresholds, |d| >= 1e-4 / (|e1||e2|): build_bvh sets it from the scene's size
     // (infinite, i.e. no clamp, for astronomically large scenes, whose axis-parallel rays then lose that axis' culling).
+    // (hardware reciprocal and square root, one unit in the last place: nothing here decides a hit, and E leaves room
+    // for it; the correctly rounded forms cost ten instructions each)
     const float ic = B.inv_clamp;
-    r.inv = mk(fminf(fmaxf(1.0f / d.x, -ic), ic), fminf(fmaxf(1.0f / d.y, -ic), ic), fminf(fmaxf(1.0f / d.z, -ic), ic));
-    r.dlen = sqrtf(dot(d, d));
-    float il = 1.0f / r.dlen;
+    r.inv = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -ic), ic), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -ic), ic),
+               fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -ic), ic));
+    r.dlen = __builtin_amdgcn_sqrtf(dot(d, d));
+    float il = __builtin_amdgcn_rcpf(r.dlen);
     r.dhat = d * il;
     if (!(r.dlen < 3.0e38f) || !(il < 3.0e38f)) { r.dlen = 3.0e38f; r.dhat = mk(0.f, 0.f, 0.f); }   // loose bound only
     r.E = 1.0e-6f * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + B.scene_mag) + 1.0e-30f;
@@ -1106,9 +1109,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // ---------------------------------------------------------------------------------------
 // AO: the kernel also traces the occlusion rays of HIPEXEC_FLAG_AO (a variant of its own, so that the default kernel does
 // not carry that loop's registers)
-// WAVES: waves per SIMD the kernel is compiled for.  5 (96 VGPRs) for few lamps; with many lamps the kernel is one long
-// run of traversals whose latency is worth a sixth wave although the compiler then keeps 31 values in scratch (80 VGPRs):
-// C5 (16 lamps) 25.6 -> 24.3 ms, C2 / C3 / C4 (1-2 lamps) 1-2 % slower at 6.
+// WAVES: waves per SIMD the kernel is compiled for: 5 (96 VGPRs) for one lamp, 6 (80 VGPRs, 25 values in scratch around the
+// lamp loop, none inside the traversal loop) from two lamps up: the kernel is then a run of traversals whose latency is
+// worth the sixth wave (C5, 16 lamps: -5 %; C2 / C3, 2 lamps: -0.7 %; C4, 1 lamp: +0.5 % at 6).
 template <int MODE, bool FUSED, int BS, bool AO = false, int WAVES = RT_SHADOW_WAVES>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
