@@ -540,7 +540,8 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             // record comes through the scalar cache (one fetch per wave) and the texture-address units are left to the
             // steps whose lanes have spread out.
             const unsigned long long m_inner = __ballot(at_inner);
-            const uint32_t lead_node = (uint32_t)__shfl((int)node, __ffsll((long long)m_inner) - 1);
+            // (v_readlane with the scalar lane number: a shuffle here is a ds_bpermute, a trip through the LDS pipe in every step)
+            const uint32_t lead_node = (uint32_t)__builtin_amdgcn_readlane((int)node, __ffsll((long long)m_inner) - 1);
             // (nodes_sc: the node array as a restrict-qualified kernel argument; only then can the compiler prove that
             // the kernel's own stores do not touch it and use scalar loads)
             const bool uniform = nodes_sc != nullptr && __ballot(at_inner && node == lead_node) == m_inner;
@@ -685,7 +686,7 @@ DEV bool bvh_packet(const DBvh &B, const TRay &r, f3 o, f3 d, bool valid, float 
                 rep[k] = __builtin_inff();
                 if (votes[k]) {
                     int leader = __ffsll((long long)votes[k]) - 1;
-                    rep[k] = fminf(__shfl(tk[k], leader), 3.0e38f);
+                    rep[k] = fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(tk[k]), leader)), 3.0e38f);
                     if (which < 0 || rep[k] < rep_best) { which = k; rep_best = rep[k]; }
                 }
             }
