@@ -853,11 +853,22 @@ __global__ __launch_bounds__(256) void k_raygen(DScene S, Frame F, float4 *__res
 // Summed per wave, then per block in LDS, so a block issues at most three global atomics; every
 // thread of the block must call this (it contains barriers).
 DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, uint32_t n_tris, uint32_t n_rays) {
+    unsigned long long a = wave_sum_u32(n_nodes & 0x7fffffffu), b = wave_sum_u32(n_tris), c = wave_sum_small(n_nodes >> 31);
+    unsigned long long r = wave_sum_u32(n_rays);
+    // blocks add to one of CNT_STRIPES copies of the counters (atomics on one address are serialised by the L2)
+    counters += (size_t)(blockIdx.x & (CNT_STRIPES - 1u)) * CNT_STRIDE;
+    if (blockDim.x == 64u) {                          // one wave: its sums are the block's
+        if (threadIdx.x == 0) {
+            if (a) atomicAdd(&counters[8 + klass], a);
+            if (b) atomicAdd(&counters[11 + klass], b);
+            if (c) atomicAdd(&counters[15], c);
+            if (r) atomicAdd(&counters[14], r);
+        }
+        return;
+    }
     __shared__ unsigned long long block_sum[4];
     if (threadIdx.x < 4) block_sum[threadIdx.x] = 0ull;
     __syncthreads();
-    unsigned long long a = wave_sum_u64(n_nodes & 0x7fffffffu), b = wave_sum_u64(n_tris), c = wave_sum_u64(n_nodes >> 31);
-    unsigned long long r = wave_sum_u64(n_rays);
     if ((threadIdx.x & 63u) == 0) {
         if (a) atomicAdd(&block_sum[0], a);
         if (b) atomicAdd(&block_sum[1], b);
@@ -866,8 +877,6 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // blocks add to one of CNT_STRIPES copies of the counters (atomics on one address are serialised by the L2)
-        counters += (size_t)(blockIdx.x & (CNT_STRIPES - 1u)) * CNT_STRIDE;
         if (block_sum[0]) atomicAdd(&counters[8 + klass], block_sum[0]);
         if (block_sum[1]) atomicAdd(&counters[11 + klass], block_sum[1]);
         if (block_sum[2]) atomicAdd(&counters[15], block_sum[2]);

@@ -503,6 +503,24 @@ DEV uint32_t block_append(bool pred, uint32_t *counter, uint32_t *scratch) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Sum of a small value over the 64 lanes of a converged wave (the sum must fit 32 bits), the same in every lane:
+// inclusive scan inside the rows of 16 lanes (row_shr 1, 2, 4, 8), row totals passed on (row_bcast 15, 31), total read
+// from lane 63.  Six DPP additions, no trip through the LDS pipe (a shuffle-based reduction is six ds_bpermute deep).
+DEV uint32_t wave_sum_small(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+// the same for any 32-bit value: its halves are summed separately, so nothing can overflow
+DEV unsigned long long wave_sum_u32(uint32_t v) {
+    return (unsigned long long)wave_sum_small(v & 0xffffu) + ((unsigned long long)wave_sum_small(v >> 16) << 16);
+}
+
 DEV unsigned long long wave_sum_u64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;   // valid in lane 0
