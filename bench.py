@@ -36,7 +36,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HIPEXEC_KNOBS", "1")     # the library honours HIPEXEC_* knobs (HIPEXEC_NO_CULL of the brute-force leg) only with this set
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test of the reference's scans
-F_NODE = 190.0                       # FLOP per visited hierarchy node (cone term + four enlarged-box slab tests of 46, see bvh_box)
+F_NODE = 121.0                       # FLOP per visited hierarchy node: growth factor 9 (bvh_node_growth) + four slab tests of 28 (bvh_box:
+                                     # 3 centre - origin, 5 corner distance, 2 growth, 3 half extents, 3 products, 6 fused multiply-adds);
+                                     # maxima, minima, comparisons and the stack carry none
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X vector FP32 peak (packed FMA: 256 CU x 4 SIMD x 16 lanes x 2 x 2 FLOP x 2.4 GHz)
 # Packed-FP32 filter of the index-order scans, FLOP per lane: camera / lamp-line records take 3 packed multiplies
 # (2 FLOP per lane each) + 6 packed FMAs (4 each) per PAIR of triangles and ray; the records for arbitrary rays
