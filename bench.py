@@ -318,10 +318,10 @@ def main(argv=None):
     if args.algo == "brute":
         os.environ["HIPEXEC_NO_CULL"] = "1"
     algo = "bvh" if args.algo == "bvh" else "scan"
-    # Throughput mode: two executors of the scene, one lane each, take the frames in turn, so that the thinly populated
+    # Throughput mode: several executors of the scene, one lane each, take the frames in turn, so that the thinly populated
     # deep recursion levels of one frame run beside the large launches of the next (the scans gain nothing from it).
-    # (two at N = 1: the chip is full and more only lengthen every launch; four for the small shares of N > 1)
-    in_flight = (args.frames_in_flight or (2 if world == 1 else 4)) if algo == "bvh" else 1
+    # (three at N = 1: C2 3.14 ms with two, 3.09 with three, 3.10 with four; four for the small shares of N > 1)
+    in_flight = (args.frames_in_flight or (3 if world == 1 else 4)) if algo == "bvh" else 1
     pipe = FramesInFlight(fs, device=local_rank, depth=in_flight, lanes=args.lanes_per_frame or None)
     os.environ.pop("HIPEXEC_NO_CULL", None)
     ex = pipe.ex[0]
@@ -434,7 +434,7 @@ def main(argv=None):
                 "isolated": {"avg_launch_ms": probe_ms[dom] / max(1, probe_launches),
                              "frac": probe_exec / max(probe_ms[dom], 1e-9) / 1e9 / PEAK_FP32_VALU_TFLOPS,
                              "note": "the same launches in a frame that has the GPU to itself (the untimed probe frame); in the timed region "
-                                     "launches of two frames overlap, so each takes longer while the frame rate is higher"},
+                                     "launches of the frames in flight overlap, so each takes longer while the frame rate is higher"},
                 "whole_frame": {"achieved": agg["exec_flop_all"] / max(elapsed, 1e-12) / 1e12, "frac": agg["exec_flop_all"] / max(elapsed, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                                 "note": "executed FLOP of all three ray classes of this rank / wall time of the timed region: what the chip "
                                         "delivered while launches of several frames shared it (the per-launch figure above divides by "
@@ -451,7 +451,7 @@ def main(argv=None):
                                             "triangle per closest-hit ray, up to the first occluder per shadow ray) / the same kernel time: an "
                                             "algorithm ratio, not a hardware fraction"}}
         if lanes > 1 or in_flight > 1:
-            roof["lanes_note"] = ("launches of concurrent streams overlap (two frames in flight on an executor each, or the two lanes of one "
+            roof["lanes_note"] = ("launches of concurrent streams overlap (frames in flight on an executor each, or the two lanes of one "
                                   "frame); kernel times are per-launch HIP-event durations and sum to more than ms_per_step")
         res = {
             "metric": "Mrays/sec (primary+secondary)", "value": rays_total / elapsed_max / 1e6, "unit": "Mrays/s",
