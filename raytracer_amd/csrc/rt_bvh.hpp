@@ -342,22 +342,30 @@ struct TRay { f3 o, inv, dhat; float dlen, E; };
 DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {
     TRay r;
     r.o = o;
-    // A direction component of (nearly) zero would make its slab terms infinite and their differences NaN.  The
-    // reciprocals are clamped to +-inv_clamp instead: an origin outside such a slab still gives an empty interval
-    // (of the order of inv_clamp * distance, far beyond any ray parameter), an origin inside one that reaches past every
-    // parameter at which a hit can be accepted.  For that the clamp must exceed 6e6 / |d| for the shortest direction
-    // that can still pass the |det| thresholds, |d| >= 1e-4 / (|e1||e2|): build_bvh sets it from the scene's size
-    // (infinite, i.e. no clamp, for astronomically large scenes, whose axis-parallel rays then lose that axis' culling).
+    // A direction component of (nearly) zero makes its reciprocal huge or infinite.  An infinite one is harmless: every
+    // term of that axis is then +-inf or NaN, and a NaN drops out of the max3 / min3 of bvh_box (the axis no longer culls).
+    // A huge finite one is not: centre * reciprocal overflows to inf while the fused half-extent term stays finite, and
+    // the axis would wrongly report an empty interval.  So reciprocals are limited to +-inv_clamp where products with them
+    // stay finite (|centre - origin| <= Q, the ray's distance scale), and become infinite where they would not:
+    //  * clamped, an origin outside such a slab still gives an empty interval (of the order of inv_clamp * distance, far
+    //    beyond any ray parameter), an origin inside one that reaches past every parameter at which a hit can be accepted;
+    //    for that the clamp must exceed 6e6 / |d| for the shortest direction that can still pass the |det| thresholds,
+    //    |d| >= 1e-4 / (|e1||e2|): build_bvh sets inv_clamp from the scene's size;
+    //  * where inv_clamp * Q leaves the float range (astronomically large scenes, far-away origins) every reciprocal above
+    //    1e37 / Q counts as infinite, and axis-parallel rays lose that axis' culling.
     // (hardware reciprocal and square root, one unit in the last place: nothing here decides a hit, and E leaves room
     // for it; the correctly rounded forms cost ten instructions each)
-    const float ic = B.inv_clamp;
-    r.inv = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(d.x), -ic), ic), fminf(fmaxf(__builtin_amdgcn_rcpf(d.y), -ic), ic),
-               fminf(fmaxf(__builtin_amdgcn_rcpf(d.z), -ic), ic));
+    const float Q = ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + B.scene_mag;
+    const float lim = 1.0e37f * __builtin_amdgcn_rcpf(Q), ic = B.inv_clamp;
+    const float thr = fminf(ic, lim), cap = (ic <= lim) ? ic : __builtin_inff();
+    float vx = __builtin_amdgcn_rcpf(d.x), vy = __builtin_amdgcn_rcpf(d.y), vz = __builtin_amdgcn_rcpf(d.z);
+    r.inv = mk(fabsf(vx) > thr ? copysignf(cap, vx) : vx, fabsf(vy) > thr ? copysignf(cap, vy) : vy,
+               fabsf(vz) > thr ? copysignf(cap, vz) : vz);
     r.dlen = __builtin_amdgcn_sqrtf(dot(d, d));
     float il = __builtin_amdgcn_rcpf(r.dlen);
     r.dhat = d * il;
     if (!(r.dlen < 3.0e38f) || !(il < 3.0e38f)) { r.dlen = 3.0e38f; r.dhat = mk(0.f, 0.f, 0.f); }   // loose bound only
-    r.E = 1.0e-6f * (((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + B.scene_mag) + 1.0e-30f;
+    r.E = 1.0e-6f * Q + 1.0e-30f;
     return r;
 }
 

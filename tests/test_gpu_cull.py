@@ -308,6 +308,45 @@ def test_astronomic_coordinates_nan_candidates():
         assert (ref["id"] >= 0).any()
 
 
+@pytest.mark.parametrize("log2_scale", [20, 32, 40, 48])
+def test_scaled_soups_axis_parallel_rays(log2_scale):
+    """A soup scaled by 2^20 ... 2^48 (exact in binary32, so the geometry is the same at every size).  The slab test of the
+    hierarchy clamps the reciprocals of the direction to a bound that grows with the square of the scene's size and drops
+    the clamp where that bound leaves the float range; axis-parallel and nearly axis-parallel rays (reciprocals at the
+    clamp, or infinite without it) must get the oracle's answers in every regime."""
+    from raytracer_amd.executor import HipExecutor
+    from raytracer_amd.scene import FlatScene, cross_f32, normalize_f32
+    from oracle.binding import Oracle
+    base = scenegen.scene_soup(seed=131, n_tri=300, extent=10.0).to_flat()
+    k = np.float32(2.0 ** log2_scale)
+    fs = FlatScene()
+    fs.tri_p = np.asarray(base.tri_p, np.float32).reshape(-1, 3) * k
+    fs.tri_e1 = np.asarray(base.tri_e1, np.float32).reshape(-1, 3) * k
+    fs.tri_e2 = np.asarray(base.tri_e2, np.float32).reshape(-1, 3) * k
+    with np.errstate(all="ignore"):
+        fs.tri_norm = normalize_f32(cross_f32(fs.tri_e1, fs.tri_e2))
+    fs.tri_mat = np.full(fs.tri_p.shape[0], -1, np.int32)
+    fs.cam_pos = np.zeros(3, np.float32)
+    fs = fs.normalised()
+    rays = _adversarial_rays(fs, 131 + log2_scale, n_each=200)
+    # short directions too: |d| down to where the determinant threshold of the exact tests ends every hit
+    rays = np.concatenate([rays, rays * np.array([1, 1, 1, 1e-9, 1e-9, 1e-9], np.float32)], 0)
+    rays = np.ascontiguousarray(rays[np.isfinite(rays).all(1)], np.float32)
+    orc = Oracle(fs)
+    with HipExecutor(fs, device=0) as ex:
+        hits = 0
+        for mode in (CPU, CL):
+            ref = orc.closest_hits(rays, mode); ref_any = orc.any_hits(rays, mode) != 0
+            hits += int((ref["id"] >= 0).sum())
+            for algo in ("bvh", "scan"):
+                ex.set_algorithm(algo)
+                got = ex.closest_hits(rays, mode)
+                assert np.array_equal(got["id"], ref["id"]), (mode, algo, int((got["id"] != ref["id"]).sum()))
+                assert np.array_equal(got["t"].view(np.int32), ref["t"].view(np.int32)), (mode, algo)
+                assert np.array_equal(ex.any_hits(rays, mode) != 0, ref_any), (mode, algo)
+        assert hits > 100
+
+
 @pytest.mark.parametrize("form", ["word", "bool"])
 def test_lane_flag_forms_give_the_oracles_answers(form):
     """Regression test of the lane-flag episode: a traversal whose per-lane `found` flag was a `bool` lost occluders
