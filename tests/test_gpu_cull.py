@@ -308,9 +308,9 @@ def test_astronomic_coordinates_nan_candidates():
         assert (ref["id"] >= 0).any()
 
 
-@pytest.mark.parametrize("log2_scale", [20, 32, 40, 48])
+@pytest.mark.parametrize("log2_scale", [-44, -24, 20, 32, 40, 48])
 def test_scaled_soups_axis_parallel_rays(log2_scale):
-    """A soup scaled by 2^20 ... 2^48 (exact in binary32, so the geometry is the same at every size).  The slab test of the
+    """A soup scaled by 2^-44 ... 2^48 (exact in binary32, so the geometry is the same at every size).  The slab test of the
     hierarchy clamps the reciprocals of the direction to a bound that grows with the square of the scene's size and drops
     the clamp where that bound leaves the float range; axis-parallel and nearly axis-parallel rays (reciprocals at the
     clamp, or infinite without it) must get the oracle's answers in every regime."""
@@ -344,7 +344,7 @@ def test_scaled_soups_axis_parallel_rays(log2_scale):
                 assert np.array_equal(got["id"], ref["id"]), (mode, algo, int((got["id"] != ref["id"]).sum()))
                 assert np.array_equal(got["t"].view(np.int32), ref["t"].view(np.int32)), (mode, algo)
                 assert np.array_equal(ex.any_hits(rays, mode) != 0, ref_any), (mode, algo)
-        assert hits > 100
+        assert hits > 100 or log2_scale < 0        # (a tiny scene is below the determinant threshold for most directions)
 
 
 @pytest.mark.parametrize("form", ["word", "bool"])
