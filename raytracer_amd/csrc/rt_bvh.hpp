@@ -39,6 +39,9 @@ constexpr int BVH_LEAF_MAX = 2;
 #ifndef RT_CLOSEST_WAVES
 #define RT_CLOSEST_WAVES 7
 #endif
+#ifndef RT_SCHED_W
+#define RT_SCHED_W 16                           // step scheduling weight of the per-lane walk, see bvh_traverse
+#endif
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 5
 #endif
@@ -733,7 +736,7 @@ DEV bool bvh_traverse(const DBvh &B, const TRay &r, f3 o, f3 d, float limit, Bes
     TState st; st.node = B.root; st.sp = 0; st.limit = limit; st.found = 0u; st.overflow = 0u;
     // step scheduling weight 16: the wave takes the leaf step unless twice as many lanes wait for an inner-node step
     // (a leaf step is what ends rays and shrinks limits; measured against 8, plain majority: C2 -2 %, C3 -2.5 %)
-    bvh_burst<MODE, ANY, BS>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, 16, nodes_sc);
+    bvh_burst<MODE, ANY, BS>(B, r, o, d, st, best, stk, 1, n_nodes, n_tris, RT_SCHED_W, nodes_sc);
     if (st.overflow) {
         n_nodes |= 0x80000000u;                 // flag for bvh_count: this lane fell back to the linear scan
         st.found = bvh_linear<MODE, ANY>(B, o, d, best, n_tris) ? 1u : 0u;
