@@ -30,9 +30,10 @@ sys.path.insert(0, ROOT)
 
 # Hardware queues of this process (HIP's default is 4; read by the runtime when it starts): every executor with a frame in
 # flight has a stream of its own (two with a side stream), torch and RCCL bring theirs.  Streams beyond the queues share one
-# and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8 with four frames in flight:
-# 0.68 ms with 4 queues, 0.60-0.63 ms with 8 (whole frames: no difference).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8: four frames in flight 0.68 ms with 4
+# queues, 0.60-0.63 ms with 8 (round-2 first part); current kernels 0.50 ms with four frames and 8 queues, 0.48 ms with
+# eight frames and 16 queues (whole frames: no difference).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1") or 1) >= 4 else "8")
 os.environ.setdefault("HIPEXEC_KNOBS", "1")     # the library honours HIPEXEC_* knobs (HIPEXEC_NO_CULL of the brute-force leg) only with this set
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test of the reference's scans
@@ -284,7 +285,7 @@ def main(argv=None):
     ap.add_argument("--no-brute", action="store_true", help="leave out the roofline_brute leg (1 warm-up + 2 frames of full scans)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--lanes-per-frame", type=int, default=0, help="lanes of each executor (0: 1 with frames in flight, else 2)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=list(range(0, 9)),
                     help="executors that take the frames in turn (hierarchy algorithm; 1: one executor with two lanes per frame)")
     ap.add_argument("--selftest-cpu", action="store_true", help="functional check of the multi-process path on CPU (gloo), no GPU")
     args = ap.parse_args(argv)
@@ -320,8 +321,9 @@ def main(argv=None):
     algo = "bvh" if args.algo == "bvh" else "scan"
     # Throughput mode: several executors of the scene, one lane each, take the frames in turn, so that the thinly populated
     # deep recursion levels of one frame run beside the large launches of the next (the scans gain nothing from it).
-    # (three at N = 1: C2 3.14 ms with two, 3.09 with three, 3.10 with four; four for the small shares of N > 1)
-    in_flight = (args.frames_in_flight or (3 if world == 1 else 4)) if algo == "bvh" else 1
+    # (three at N = 1: C2 3.14 ms with two, 3.09 with three, 3.10 with four; four for the shares of N = 2 and 3, eight for the
+    # small shares from N = 4 up: rank 0's share of C2 at G = 4 0.91 -> 0.88 ms, at G = 8 0.50 -> 0.48 ms)
+    in_flight = (args.frames_in_flight or (3 if world == 1 else 4 if world < 4 else 8)) if algo == "bvh" else 1
     pipe = FramesInFlight(fs, device=local_rank, depth=in_flight, lanes=args.lanes_per_frame or None)
     os.environ.pop("HIPEXEC_NO_CULL", None)
     ex = pipe.ex[0]
