@@ -30,9 +30,9 @@ sys.path.insert(0, ROOT)
 
 # Hardware queues of this process (HIP's default is 4; read by the runtime when it starts): every executor with a frame in
 # flight has a stream of its own (two with a side stream), torch and RCCL bring theirs.  Streams beyond the queues share one
-# and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8: four frames in flight 0.68 ms with 4
-# queues, 0.60-0.63 ms with 8 (round-2 first part); current kernels 0.50 ms with four frames and 8 queues, 0.48 ms with
-# eight frames and 16 queues (whole frames: no difference).
+# and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8: 0.50 ms with four frames in flight and 8
+# queues, 0.48 ms with eight frames and 16 queues; with 4 queues and four frames 13 % slower than with 8 (whole frames: no
+# difference).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1") or 1) >= 4 else "8")
 os.environ.setdefault("HIPEXEC_KNOBS", "1")     # the library honours HIPEXEC_* knobs (HIPEXEC_NO_CULL of the brute-force leg) only with this set
 

@@ -62,3 +62,15 @@ def test_product_package_never_imports_the_oracle():
         assert not pat.search(open(path).read()), f"{path} uses the oracle"
     for path in glob.glob(os.path.join(ROOT, "raytracer_amd", "csrc", "*")):
         assert not pat.search(open(path).read()), f"{path} uses the oracle"
+
+
+def test_build_flags_keep_the_exact_arithmetic_exact():
+    """The exact tests must be compiled without contraction into fused multiply-adds and with correctly rounded division
+    and square root (the reference's x86 build rounds after every operation), and without fast-math of any kind."""
+    import __graft_entry__ as g
+    flags = g.HIPCC_FLAGS
+    assert "-ffp-contract=off" in flags
+    assert "-fhip-fp32-correctly-rounded-divide-sqrt" in flags
+    assert not any(f.startswith("-ffast-math") or f.startswith("-Ofast") or f.startswith("-funsafe-math") or
+                   f.startswith("-ffinite-math") or f.startswith("-fno-signed-zeros") for f in flags)
+    assert "--offload-arch=gfx950" in flags
