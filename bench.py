@@ -429,6 +429,9 @@ def main(argv=None):
                                "triangle test + 25 per sphere test") if algo == "bvh" else
                               ("packed-FP32 filter instructions the kernel executed (30 or 66 FLOP per lane, triangle pair and ray; "
                                "packed FMA = 4 FLOP per lane), exact tests of survivors left out"),
+                "flop_model_note": ("a fraction of the FLOP peak rewards instructions, not results: shortening the node step from 190 to 121 FLOP "
+                                    "made the frame faster and this fraction smaller; the kernels are bound by their vector-instruction count "
+                                    "(see pmc: rocprof VALUBusy)") if algo == "bvh" else None,
                 "avg_launch_ms": agg["ms"] / max(1, agg["launches"]), "launches_per_step": agg["launches"] / args.steps,
                 "kernel_ms_per_step": {f"{names[k]} ({KLABEL[k]})": probe_ms[k] for k in range(4)},
                 "kernel_ms_note": "all classes: one untimed frame with every launch timed; the timed steps time the dominant class only",
