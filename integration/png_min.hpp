@@ -3,7 +3,8 @@
 // byte: colour types 0/2/3/4/6 at every legal bit depth, tRNS keys compared at full sample width, 16-bit
 // samples reduced to their high byte, sub-byte grey scaled by 255/(2^depth - 1), Adam7 interlacing, a palette
 // index beyond the palette read as opaque black; chunk CRCs are verified and an unknown critical chunk, a bad
-// filter type, a colour type / depth pair the format does not allow or truncated data are errors.
+// filter type, a colour type / depth pair the format does not allow, truncated data or a header that announces more
+// than 2^28 - 1 pixels (or a 32-bit pixel count that wraps) are errors.
 #pragma once
 #include <zlib.h>
 
@@ -56,6 +57,13 @@ inline ImageRGBA8 decode_png(const std::vector<uint8_t> &file, const std::string
         pos += 12 + (size_t)len;
     }
     if (W == 0 || H == 0 || ctype < 0) fail("missing IHDR");
+    // Size limit of the reference's decoder (lodepng.cpp:4547-4553): the pixel count is formed in 32 bits, a product that
+    // wraps is rejected, and so is anything above 2^28 - 1 pixels.  Every size computed below then fits 64 bits with room
+    // to spare (at most 2^28 pixels x 8 bytes + 2^28 filter bytes), and no crafted header can make the buffers disagree.
+    {
+        const uint32_t numpixels = W * H;                       // wraps like the reference's `unsigned` product
+        if (numpixels / H != W || numpixels > 268435455u) fail("image too large");
+    }
     if (interlace > 1) fail("unknown interlace method");
     int channels;
     switch (ctype) {

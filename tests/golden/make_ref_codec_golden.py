@@ -146,6 +146,18 @@ def cases():
     flt = bytearray(filter_rows(pack_rows(s.reshape(5, 15), 8), 3, 0)); flt[16] = 7            # filter type 7 on row 1
     comp = zlib.compress(bytes(flt))
     out["bad_filter_type"] = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 5, 5, 8, 2, 0, 0, 0)) + chunk(b"IDAT", comp) + chunk(b"IEND", b""))
+
+    # headers that announce more pixels than a decoder may size its buffers for (valid CRCs, a few bytes of image data):
+    # a 32-bit pixel count that wraps to 0, one that wraps to a small number, one just above and one exactly at 2^28 - 1
+    def header_only(w, h, depth, ctype, interlace=0):
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+                + chunk(b"IDAT", zlib.compress(bytes(64))) + chunk(b"IEND", b""))
+    out["huge_wraps_to_zero_rgba16"] = header_only(0x80000000, 0x80000000, 16, 6)
+    out["huge_65536x65536_rgb8"] = header_only(65536, 65536, 8, 2)
+    out["huge_wraps_to_small_grey8"] = header_only(0x10001, 0x10000, 8, 0)       # 2^32 + 2^16 pixels: 65536 after the wrap
+    out["huge_wraps_interlaced"] = header_only(0xFFFFFFFF, 0xFFFFFFFF, 8, 6, 1)
+    out["big_above_limit_grey1"] = header_only(16384, 16384, 1, 0)               # 2^28 pixels
+    out["big_at_limit_grey1"] = header_only(16383, 16385, 1, 0)                  # 2^28 - 1 pixels: sized, then the data is too short
     return out
 
 
