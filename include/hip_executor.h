@@ -160,7 +160,7 @@ typedef struct hipexec_render_cfg {
  * colours; they differ in which tests they can prove unnecessary. */
 enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };
 
-#define HIPEXEC_ABI_VERSION 4
+#define HIPEXEC_ABI_VERSION 5
 
 /* Kernel classes reported in hipexec_stats. */
 enum {
@@ -229,6 +229,28 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
  * hipexec_create() on that device is served: the reference makes and destroys an executor inside every renderSceneCl
  * call (ray_tracer_cl.cpp:14), and allocation would otherwise cost more than the frame. */
 void hipexec_destroy(hipexec_t *h);
+
+/*
+ * A further executor of the SAME scene on the same device: it shares the device copy of the scene, the textures and the
+ * hierarchy of `src` (no upload, no build; the memory is released when the last executor of the scene is destroyed) and
+ * has streams, work buffers, counters and a camera of its own, so its calls may overlap those of `src` and of other
+ * clones.  No counterpart in the reference, whose one executor renders one frame at a time (ray_tracer_cl.cpp:14-55);
+ * this is how a caller keeps K frames in flight (hipexec_render_device on K executors in turn) without K copies of the
+ * scene.  The clone starts with the camera, algorithm and lane count `src` has at that moment.  `src` may be destroyed
+ * before its clones.  Set-up calls that may add scene memory (hipexec_set_algorithm to the scans, the first scanning
+ * call) must not run on two executors of one scene at the same time.
+ */
+int hipexec_clone(hipexec_t **out, hipexec_t *src);
+
+/*
+ * Camera of later calls of this executor: position and the 3x3 matrix in the layout of hipexec_scene_desc
+ * (cam_pos[3], cam_mat[9]); what scene.cpp:121-134 reads from "translate" / "transform".  The reference takes the
+ * camera from the Scene it is handed with every call (ray_tracer_cl.cpp:80-92); an executor holds the camera of the
+ * scene it was created from until this call changes it.  Nothing of the hierarchy depends on the camera, so the call
+ * costs a few stores (with the scan algorithm selected: one pass over the triangles for its camera records).  A frame
+ * in flight on this executor is waited for first.
+ */
+int hipexec_set_camera(hipexec_t *h, const float *cam_pos, const float *cam_mat);
 
 /*
  * Returns what the library's pool holds for `device` (-1: every device) to the driver.  No counterpart in the

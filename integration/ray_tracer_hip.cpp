@@ -39,15 +39,30 @@ public:
     explicit OpenClExecutor(const Scene &scene) : flat_(scene)
     {
         checkHipResult(hipexec_create(&handle_, &flat_.desc(), -1), "hipexec_create");
+        std::copy(flat_.desc().cam_pos, flat_.desc().cam_pos + 3, cam_pos_);
+        std::copy(flat_.desc().cam_mat, flat_.desc().cam_mat + 9, cam_mat_);
     }
     ~OpenClExecutor() { hipexec_destroy(handle_); }
     OpenClExecutor(const OpenClExecutor &) = delete;
     OpenClExecutor &operator=(const OpenClExecutor &) = delete;
     hipexec_t *handle() const { return handle_; }
+    // points the executor's device-side ray generation at the camera of `scene` if it is not already there
+    void useCameraOf(const Scene &scene)
+    {
+        float pos[3] = {scene.camPos.x, scene.camPos.y, scene.camPos.z}, mat[9];
+        for (int i = 0; i < 3; i++) for (int c = 0; c < 3; c++) mat[3 * i + c] = scene.camMat[i][c];
+        bool same = true;
+        for (int k = 0; k < 3; k++) same = same && pos[k] == cam_pos_[k];
+        for (int k = 0; k < 9; k++) same = same && mat[k] == cam_mat_[k];
+        if (same) return;
+        checkHipResult(hipexec_set_camera(handle_, pos, mat), "hipexec_set_camera");
+        std::copy(pos, pos + 3, cam_pos_); std::copy(mat, mat + 9, cam_mat_);
+    }
 
 private:
     rt_hip::FlatScene<Scene> flat_;
     hipexec_t *handle_ = nullptr;
+    float cam_pos_[3], cam_mat_[9];           // the camera the executor currently renders from
 };
 
 // ray_tracer_cl.cpp:9-56.  The reference walks the frame in 48x48 blocks only to bound its
@@ -71,7 +86,10 @@ void renderSceneCl(image_bitmap &outImg, const Scene &scene)
 void renderSubBlockCl(image_bitmap &outImg, const Scene &scene, std::shared_ptr<OpenClExecutor> clExecutor,
                       int x, int y, int w, int h, int fullWidth, int fullHeight)
 {
-    (void)scene;
+    // The reference makes the block's rays from the scene passed to THIS call (ray_tracer_cl.cpp:80-92); its own driver
+    // always passes the scene the executor was built from.  A caller that hands over another camera gets that camera:
+    // the executor's device-side ray generation is pointed at it first (the geometry stays the executor's).
+    clExecutor->useCameraOf(scene);
     hipexec_render_cfg cfg{};
     cfg.width = fullWidth; cfg.height = fullHeight;
     cfg.mode = HIPEXEC_MODE_CL; cfg.max_depth = 0; cfg.tone = 1;

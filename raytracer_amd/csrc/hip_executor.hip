@@ -273,18 +273,33 @@ static_assert(N_CNT64 <= (int)CNT_STRIDE, "counters fit a stripe");
 constexpr int LV_SLOTS = 8;                                  // batches of one call (per lane) whose level counts are kept apart
 constexpr int LV_PER = 68;                                   // level counters per batch: entry L = rays queued for recursion level L (max_depth <= 64)
 
-// Ray-queue sizes of the recursion levels of one batch, remembered per executor lane.  Rendering is deterministic, so a
-// batch with the same key has the same queue sizes every time: the second and later frames size every launch from
-// the remembered counts and never wait for a count to come back from the device; the counts the kernels produced are
-// compared with the remembered ones when the call is collected, and a difference repeats the frame the waiting way.
+// Ray-queue sizes of the recursion levels of one batch, as the last frame with the same key produced them, kept per
+// executor lane.  No frame of the hierarchy algorithm waits for a count to come back from the device: every launch of
+// a level is sized on the host, the kernels clamp to the queue's true fill on the device (queue_fill), and a launch
+// that is larger than its queue costs only blocks that exit at once.  The sizes come from
+//   * the bound n(L+1) <= n(L) (a ray has at most one successor) when nothing is remembered: first frame of a
+//     configuration, or the repeat of a frame whose sizes proved too small;
+//   * the remembered sizes themselves when the last two frames with this key agreed (a static scene and camera repeat
+//     exactly: rendering is deterministic);
+//   * the remembered sizes plus a margin, capped by the bound, otherwise (a moving camera).
+// The sizes the kernels produced come back with the frame and are compared with what was launched when the call is
+// collected: only a level that was launched too SMALL has lost rays, and only then the frame is traced again (from
+// the bound, which cannot be too small).  Decisions that depend on a launch size (threads per block, tail kernel,
+// side stream) change speed, never bits.
 struct LevelPred {
     std::array<int64_t, 24> key{};
-    std::vector<uint32_t> n;                                  // n[L], L >= 1, for the levels that were traced
+    std::vector<uint32_t> n;                                  // n[L], L >= 1: queue sizes the last frame with this key produced
+    bool steady = false;                                      // the frame before produced the same sizes
 };
-struct LevelCheck { int slot; std::array<int64_t, 24> key; };
+struct LevelCheck { int slot; std::array<int64_t, 24> key; std::vector<uint32_t> launched; };
+// How the launches of a batch's levels get their sizes.
+enum { SIZE_AUTO = 0,      // from remembered sizes where they exist, else from the bound
+       SIZE_BOUND = 1,     // from the bound n(L+1) <= n(L) only (repeat of a frame; HIPEXEC_PREDICT=2)
+       SIZE_WAIT = 2 };    // every size is read back from the device before the next launch (scan algorithm, batch calls, HIPEXEC_PREDICT=0)
 
 // Fixed work memory of hipexec_any_hits_static (one copy per GPU, held until the process ends):
-// [0, 256) work counters, then the ray records (32 bytes per ray), then one occlusion word per ray.
+// [0, STATIC_CNT_BYTES) the striped work counters (CNT_STRIPES x CNT_STRIDE 64-bit words = 16 KiB), then the ray
+// records (32 bytes per ray), then one occlusion word per ray.
 constexpr size_t STATIC_CNT_BYTES = CNT64_WORDS * sizeof(unsigned long long);
 constexpr size_t STATIC_REC_BYTES = (size_t)HIPEXEC_STATIC_MAX_RAYS * 32;
 constexpr size_t STATIC_OCC_BYTES = (size_t)HIPEXEC_STATIC_MAX_RAYS * 4;
@@ -302,8 +317,29 @@ unsigned char *g_static_ptr[STATIC_MAX_DEVICES] = {};
 std::mutex g_static_mutex;
 }  // namespace
 
+// Device copy of a scene and its hierarchy: owned jointly by the executor that uploaded it and the executors cloned from
+// it (hipexec_clone), released by the last of them.  Everything in it is read-only once built, except that the first
+// executor that scans adds the camera-independent scan records (under the mutex).
+struct SceneShare {
+    std::atomic<int> refs{1};
+    int device = 0;
+    std::mutex m;                             // arena and shared scan records
+    std::vector<void *> allocs;               // chunks of the scene arena
+    char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    float *d_tri_p = nullptr, *d_tri_e1 = nullptr, *d_tri_e2 = nullptr;   // the caller's triangle arrays on the device (set-up kernels read them)
+    std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
+    bool scan_shared = false;                 // pair_gen / pair_lamp / chunk_box exist
+    const PairGen *pair_gen = nullptr; const PairCam *pair_lamp = nullptr; const float4 *chunk_box = nullptr;
+    // remembered queue sizes (newest last, at most 64), common to the executors of the scene and their lanes: with
+    // several frames in flight each executor sizes its next frame from the newest frame any of them has collected
+    std::mutex pred_m;
+    std::vector<LevelPred> preds;
+};
+
 struct hipexec {
     int device = 0;
+    SceneShare *share = nullptr;              // null for helper lanes (they live inside their executor)
+    SceneShare *pred_home = nullptr;          // whose remembered queue sizes this lane uses (its executor's scene)
     hipStream_t own_stream = nullptr, stream = nullptr;
     DScene S{};
     DBvh B{};
@@ -315,13 +351,10 @@ struct hipexec {
     int refill_closest = REFILL_BELOW;        // HIPEXEC_REFILL_CLOSEST: live lanes below which a wave fetches new rays
     bool bvh_refill = true;                   // closest-hit kernel that refills idle lanes (HIPEXEC_BVH_REFILL=0: one ray per lane)
     uint32_t lamp_words = 1;
-    std::vector<void *> scene_allocs;         // chunks of the scene arena
-    char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;
     hipStream_t upload_stream = nullptr;      // stream of upload() while it is not the executor's (scene set-up: beside the hierarchy build)
     void *build_tmp = nullptr;                // temporaries of the hierarchy build, until the build has been waited for
-    float *d_tri_p = nullptr, *d_tri_e1 = nullptr, *d_tri_e2 = nullptr;   // the caller's triangle arrays on the device (set-up kernels read them)
-    std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
-    bool scan_ready = false;                  // the scan algorithm's records exist (ensure_scan_records)
+    bool scan_ready = false;                  // the scan algorithm's records exist and belong to this executor's camera (ensure_scan_records)
+    Buf cam_primx, cam_pairs;                 // the camera-dependent scan records of this executor (k_setup_cam_pairs)
     Buf rayA, rayB, hit0, hitN, hitM, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
     uint32_t *d_cnt32 = nullptr;              // [0] next-level queue fill, [1 + l] shadow queue fill of lamp l
     uint32_t n_cnt32 = 0;
@@ -331,12 +364,11 @@ struct hipexec {
     uint32_t *h_cnt32 = nullptr;              // pinned
     uint32_t *d_lvl = nullptr, *h_lvl = nullptr;   // [LV_SLOTS][LV_PER] level queue fills of the call in progress (device / pinned)
     int lv_slot = 0;                          // next free slot of the call in progress
-    std::vector<LevelPred> preds;             // remembered queue sizes (newest last, at most 64)
     std::vector<LevelCheck> checks;           // batches of the call in progress that ran from remembered sizes
-    bool predict = true;                      // HIPEXEC_PREDICT=0: always wait for the counts
+    int size_default = SIZE_AUTO;             // HIPEXEC_PREDICT=0: SIZE_WAIT, =2: SIZE_BOUND
+    int size_mode = SIZE_AUTO;                // of the call in progress (SIZE_BOUND while a frame is being repeated, SIZE_WAIT for batch calls)
     int predict_spoil = 0;                    // test hook: remembered level-1 sizes are stored this much too large (or too small)
-    bool predict_now = true;                  // false while a frame is being repeated after a failed check
-    bool redo = false;                        // a check failed: the frame has to be repeated
+    bool redo = false;                        // a level was launched too small: the frame has to be repeated
     hipexec_render_cfg pending_cfg{};         // arguments of an asynchronous call, for such a repeat
     float4 *pending_rgba = nullptr; int32_t *pending_ids = nullptr;
     unsigned long long *h_cnt64 = nullptr;    // pinned
@@ -398,16 +430,28 @@ int scene_alloc(hipexec *h, size_t bytes, void **out)
 {
     constexpr size_t CHUNK = 32u << 20, ALIGN = 256;
     bytes = (bytes + ALIGN - 1) / ALIGN * ALIGN;
-    if (h->arena_used + bytes > h->arena_cap) {
+    SceneShare *sh = h->share;
+    if (!sh) return fail(HIPEXEC_E_INVALID, "a helper lane owns no scene memory");
+    std::lock_guard<std::mutex> lk(sh->m);
+    if (sh->arena_used + bytes > sh->arena_cap) {
         size_t want = std::max(bytes, CHUNK);
         void *p = nullptr;
         CHK(pool_alloc(h->device, false, want, &p));
-        h->scene_allocs.push_back(p);
-        h->arena = static_cast<char *>(p); h->arena_cap = want; h->arena_used = 0;
+        sh->allocs.push_back(p);
+        sh->arena = static_cast<char *>(p); sh->arena_cap = want; sh->arena_used = 0;
     }
-    *out = h->arena + h->arena_used;
-    h->arena_used += bytes;
+    *out = sh->arena + sh->arena_used;
+    sh->arena_used += bytes;
     return HIPEXEC_OK;
+}
+
+// drops one reference; the last one hands the scene's memory back (the caller has synchronised its streams)
+void share_release(SceneShare *sh)
+{
+    if (!sh) return;
+    if (sh->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    for (void *p : sh->allocs) pool_free(sh->device, false, p);
+    delete sh;
 }
 
 // Device array of max(count, min_count) elements: the first `count` copied from src (if any), the
@@ -621,7 +665,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     CHK(upload(h, s->tri_p, 3 * (size_t)s->n_tri, &d_p));
     CHK(upload(h, s->tri_e1, 3 * (size_t)s->n_tri, &d_e1));
     CHK(upload(h, s->tri_e2, 3 * (size_t)s->n_tri, &d_e2));
-    h->d_tri_p = d_p; h->d_tri_e1 = d_e1; h->d_tri_e2 = d_e2;
+    h->share->d_tri_p = d_p; h->share->d_tri_e1 = d_e1; h->share->d_tri_e2 = d_e2;
     float4 *ex = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &ex, 3 * (size_t)S.n_tri_pad + 1));
     if (S.n_tri_pad) {
@@ -633,7 +677,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     // the first call that scans, see ensure_scan_records: the default algorithm never reads them, and an executor that
     // is created per frame (ray_tracer_cl.cpp:14) should not pay for them.
     S.tri_primx = nullptr; S.pair_cam = nullptr; S.pair_gen = nullptr; S.pair_lamp = nullptr; S.chunk_box = nullptr;
-    h->lamp_pos_host.assign(s->lamp_pos, s->lamp_pos + 3 * (size_t)s->n_lamp);
+    h->share->lamp_pos_host.assign(s->lamp_pos, s->lamp_pos + 3 * (size_t)s->n_lamp);
     {
         const char *nc = knob("HIPEXEC_NO_CULL");       // verification / roofline aid: scan every chunk
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
@@ -746,42 +790,62 @@ inline uint32_t timing_mask(int32_t flags)
 
 inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
-// Records of the index-order scan algorithm, made once, by the first call that needs them.
+// Records of the index-order scan algorithm, made by the first call that needs them: the camera-independent ones once
+// per scene (shared by the executors cloned from one another), the camera-dependent ones per executor and again after
+// hipexec_set_camera.
 int ensure_scan_records(hipexec *h)
 {
     if (h->scan_ready) return HIPEXEC_OK;
     DScene &S = h->S;
-    float4 *px = nullptr; PairCam *pc = nullptr; PairGen *pg = nullptr;
-    float4 *ex = const_cast<float4 *>(S.tri_exact);
-    CHK(upload<float4>(h, nullptr, 0, &px, 3 * (size_t)S.n_tri_pad + 1));
-    CHK(upload<PairCam>(h, nullptr, 0, &pc, (size_t)S.n_tri_pad / 2 + 1));
-    CHK(upload<PairGen>(h, nullptr, 0, &pg, (size_t)S.n_tri_pad / 2 + 1));
-    if (S.n_tri_pad) {
-        f3 cam = {S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]}, cen = {S.center[0], S.center[1], S.center[2]};
-        hipLaunchKernelGGL(k_setup_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
-                           S.n_tri, S.n_tri_pad, h->d_tri_p, h->d_tri_e1, h->d_tri_e2, cam, cen, S.rmax, ex, px, pc, pg);   // rewrites the exact records with the same bits
-        HIPCHK(hipGetLastError());
-    }
-    PairCam *pl = nullptr;
-    CHK(upload<PairCam>(h, nullptr, 0, &pl, (size_t)S.n_lamp * (S.n_tri_pad / 2) + 1));
-    if (S.n_tri_pad) {
-        float abs_bound = S.rmax + std::sqrt(S.center[0] * S.center[0] + S.center[1] * S.center[1] + S.center[2] * S.center[2]);
-        for (uint32_t l = 0; l < S.n_lamp; l++) {
-            f3 L = {h->lamp_pos_host[3 * l], h->lamp_pos_host[3 * l + 1], h->lamp_pos_host[3 * l + 2]};
-            hipLaunchKernelGGL(k_setup_lamp_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
-                               S.n_tri, S.n_tri_pad, h->d_tri_p, h->d_tri_e1, h->d_tri_e2, L, abs_bound, pl + (size_t)l * (S.n_tri_pad / 2));
+    SceneShare *sh = h->share;
+    if (!sh) return fail(HIPEXEC_E_INVALID, "a helper lane cannot scan");
+    bool make_shared;
+    { std::lock_guard<std::mutex> lk(sh->m); make_shared = !sh->scan_shared; }
+    // (two executors of one scene must not make their first scanning call at the same time: the calls on the executors
+    // of one scene that may allocate scene memory are set-up calls, like hipexec_set_algorithm)
+    if (make_shared) {
+        PairGen *pg = nullptr;
+        CHK(upload<PairGen>(h, nullptr, 0, &pg, (size_t)S.n_tri_pad / 2 + 1));
+        if (S.n_tri_pad) {
+            f3 cen = {S.center[0], S.center[1], S.center[2]};
+            hipLaunchKernelGGL(k_setup_gen_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                               S.n_tri, S.n_tri_pad, sh->d_tri_p, sh->d_tri_e1, sh->d_tri_e2, cen, S.rmax, pg);
             HIPCHK(hipGetLastError());
         }
+        PairCam *pl = nullptr;
+        CHK(upload<PairCam>(h, nullptr, 0, &pl, (size_t)S.n_lamp * (S.n_tri_pad / 2) + 1));
+        if (S.n_tri_pad) {
+            float abs_bound = S.rmax + std::sqrt(S.center[0] * S.center[0] + S.center[1] * S.center[1] + S.center[2] * S.center[2]);
+            for (uint32_t l = 0; l < S.n_lamp; l++) {
+                f3 L = {sh->lamp_pos_host[3 * l], sh->lamp_pos_host[3 * l + 1], sh->lamp_pos_host[3 * l + 2]};
+                hipLaunchKernelGGL(k_setup_lamp_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                                   S.n_tri, S.n_tri_pad, sh->d_tri_p, sh->d_tri_e1, sh->d_tri_e2, L, abs_bound, pl + (size_t)l * (S.n_tri_pad / 2));
+                HIPCHK(hipGetLastError());
+            }
+        }
+        float4 *cb = nullptr;
+        uint32_t n_chunks = S.n_tri_pad / CHUNK_TRIS;
+        CHK(upload<float4>(h, nullptr, 0, &cb, 3 * (size_t)n_chunks + 1));
+        if (n_chunks) {
+            hipLaunchKernelGGL(k_setup_chunks, dim3((n_chunks + 63) / 64), dim3(64), 0, h->stream, S.n_tri, n_chunks, sh->d_tri_p, sh->d_tri_e1, sh->d_tri_e2, cb);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::lock_guard<std::mutex> lk(sh->m);
+        sh->pair_gen = pg; sh->pair_lamp = pl; sh->chunk_box = cb; sh->scan_shared = true;
     }
-    float4 *cb = nullptr;
-    uint32_t n_chunks = S.n_tri_pad / CHUNK_TRIS;
-    CHK(upload<float4>(h, nullptr, 0, &cb, 3 * (size_t)n_chunks + 1));
-    if (n_chunks) {
-        hipLaunchKernelGGL(k_setup_chunks, dim3((n_chunks + 63) / 64), dim3(64), 0, h->stream, S.n_tri, n_chunks, h->d_tri_p, h->d_tri_e1, h->d_tri_e2, cb);
+    { std::lock_guard<std::mutex> lk(sh->m); S.pair_gen = sh->pair_gen; S.pair_lamp = sh->pair_lamp; S.chunk_box = sh->chunk_box; }
+    // this executor's camera
+    CHK(h->cam_primx.reserve((3 * (size_t)S.n_tri_pad + 1) * sizeof(float4)));
+    CHK(h->cam_pairs.reserve(((size_t)S.n_tri_pad / 2 + 1) * sizeof(PairCam)));
+    if (S.n_tri_pad) {
+        f3 cam = {S.cam_pos[0], S.cam_pos[1], S.cam_pos[2]};
+        hipLaunchKernelGGL(k_setup_cam_pairs, dim3((S.n_tri_pad / 2 + 255) / 256), dim3(256), 0, h->stream,
+                           S.n_tri, S.n_tri_pad, sh->d_tri_p, sh->d_tri_e1, sh->d_tri_e2, cam, h->cam_primx.as<float4>(), h->cam_pairs.as<PairCam>());
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
-    S.tri_primx = px; S.pair_cam = pc; S.pair_gen = pg; S.pair_lamp = pl; S.chunk_box = cb;
+    S.tri_primx = h->cam_primx.as<float4>(); S.pair_cam = h->cam_pairs.as<PairCam>();
     h->scan_ready = true;
     return HIPEXEC_OK;
 }
@@ -860,16 +924,34 @@ int call_end(hipexec *h, hipexec_stats *stats)
     }
     h->timed.clear();
     h->call_open = false;
-    // batches that ran from remembered queue sizes: the sizes the kernels produced must be the remembered ones
+    // Batches whose launches were sized on the host: a level that produced more rays than its launch covered has lost
+    // rays, and the frame must be traced again; otherwise the sizes the kernels produced are the frame's ray counts and
+    // what the next frame with this key is sized from.
     for (const LevelCheck &c : h->checks) {
         const uint32_t *got = h->h_lvl + (size_t)c.slot * LV_PER;
-        for (size_t i = 0; i < h->preds.size(); i++) {
-            if (!(h->preds[i].key == c.key)) continue;
-            bool same = true;
-            for (size_t L = 1; L < h->preds[i].n.size(); L++) same = same && got[L] == h->preds[i].n[L];
-            if (!same) { h->preds.erase(h->preds.begin() + (long)i); h->redo = true; }
-            break;
+        bool covered = true;
+        int top = 0;
+        for (int L = 1; L < LV_PER; L++) {
+            const uint32_t launched = (size_t)L < c.launched.size() ? c.launched[(size_t)L] : 0u;
+            covered = covered && got[L] <= launched;
+            if (got[L]) top = L;
         }
+        if (!covered) { h->redo = true; continue; }
+        for (int L = 1; L <= top; L++) {
+            h->acc.rays_bounce += got[L];
+            h->acc.tests_tri_closest += (uint64_t)got[L] * h->S.n_tri;
+            h->acc.tests_sph_closest += (uint64_t)got[L] * h->S.n_sph;
+        }
+        LevelPred rec; rec.key = c.key; rec.n.assign(got, got + top + 1); rec.n[0] = 0u;
+        // test hook: a remembered size that is wrong, so that the check above and the repeat of the frame can be exercised
+        if (h->predict_spoil && rec.n.size() > 1 && (int64_t)rec.n[1] + h->predict_spoil > 0)
+            rec.n[1] = (uint32_t)((int64_t)rec.n[1] + h->predict_spoil);
+        std::lock_guard<std::mutex> lk(h->pred_home->pred_m);
+        std::vector<LevelPred> &preds = h->pred_home->preds;
+        for (size_t i = 0; i < preds.size(); i++)
+            if (preds[i].key == c.key) { rec.steady = preds[i].n == rec.n; preds.erase(preds.begin() + (long)i); break; }
+        if (preds.size() >= 64) preds.erase(preds.begin());
+        preds.push_back(rec);
     }
     h->checks.clear();
     // the other lanes' shares of the frame: their counters and kernel times are added to this call's
@@ -887,17 +969,23 @@ int call_end(hipexec *h, hipexec_stats *stats)
 // Queue sizes of the recursion levels of the batch being traced (see LevelPred).
 struct LevelRun {
     int slot = -1;                       // counters of this batch: d_lvl[slot][level]; -1: the call has more batches than slots
-    const LevelPred *pred = nullptr;     // remembered sizes to run from, or null: every size is read back (and remembered)
-    LevelPred rec;
+    bool sized = false;                  // launch sizes are chosen on the host (else: read back from the device, level by level)
+    bool have_pred = false;              // remembered sizes exist (sized runs)
+    LevelPred pred;
+    std::array<int64_t, 24> key{};
+    std::vector<uint32_t> launched;      // launched[L]: size the launches of level L were made for (sized runs)
 };
 
-int level_begin(hipexec *h, const std::array<int64_t, 24> &key, bool may_predict, LevelRun &run)
+int level_begin(hipexec *h, const std::array<int64_t, 24> &key, bool may_size, LevelRun &run)
 {
     run.slot = h->lv_slot < LV_SLOTS ? h->lv_slot++ : -1;
-    run.pred = nullptr;
-    run.rec.key = key; run.rec.n.assign(1, 0u);
-    if (run.slot >= 0 && may_predict && h->predict && h->predict_now)
-        for (const LevelPred &p : h->preds) if (p.key == key) run.pred = &p;
+    run.have_pred = false;
+    run.key = key; run.launched.assign(1, 0u);
+    run.sized = run.slot >= 0 && may_size && h->size_mode != SIZE_WAIT;
+    if (run.sized && h->size_mode == SIZE_AUTO) {
+        std::lock_guard<std::mutex> lk(h->pred_home->pred_m);
+        for (const LevelPred &p : h->pred_home->preds) if (p.key == key) { run.pred = p; run.have_pred = true; }
+    }
     return HIPEXEC_OK;
 }
 
@@ -907,40 +995,46 @@ uint32_t *level_counter(hipexec *h, const LevelRun &run, int level)
     return run.slot >= 0 ? h->d_lvl + (size_t)run.slot * LV_PER + level : h->d_cnt32;
 }
 
-// what the consumers of level `level`'s queue get as its device-side fill: the counter when the launch size is a
-// remembered one, nothing when it was read back from that counter (or is level 0, whose size the host computes)
+// what the consumers of level `level`'s queue get as its device-side fill: the counter when the launch size was chosen
+// on the host, nothing when it was read back from that counter (or is level 0, whose size the host computes)
 const uint32_t *level_fill(hipexec *h, const LevelRun &run, int level)
 {
-    return (run.pred && level >= 1) ? level_counter(h, run, level) : nullptr;
+    return (run.sized && level >= 1) ? level_counter(h, run, level) : nullptr;
 }
 
-// number of rays queued for `level`, once its producers are enqueued on `stream`
-int level_count(hipexec *h, LevelRun &run, int level, uint32_t *out)
+// Size for the launches of `level` (>= 1), once its producers are enqueued on `stream`; `prev` is the size the level
+// before was launched with, which bounds it.  `counted`: the value is the true count (the caller adds it to the ray
+// statistics; sized runs get theirs from the device counters when the call is collected).
+int level_count(hipexec *h, LevelRun &run, int level, uint32_t prev, uint32_t *out, bool *counted)
 {
-    if (run.pred) { *out = (size_t)level < run.pred->n.size() ? run.pred->n[(size_t)level] : 0u; return HIPEXEC_OK; }
+    *counted = !run.sized;
+    if (run.sized) {
+        uint32_t n = prev;                                              // the bound: at most one successor per ray
+        if (run.have_pred) {
+            const uint32_t last = (size_t)level < run.pred.n.size() ? run.pred.n[(size_t)level] : 0u;
+            // steady: exactly what the last two frames produced; otherwise an eighth more and a few blocks' worth of slack
+            const uint64_t want = run.pred.steady ? last : (uint64_t)last + last / 8u + 4096u;
+            n = (uint32_t)std::min<uint64_t>(prev, want);
+        }
+        run.launched.resize((size_t)level + 1, 0u);
+        run.launched[(size_t)level] = n;
+        *out = n;
+        return HIPEXEC_OK;
+    }
     uint32_t *src = level_counter(h, run, level);
     HIPCHK(hipMemcpyAsync(h->h_cnt32, src, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *out = h->h_cnt32[0];
-    run.rec.n.resize((size_t)level + 1, 0u);
-    run.rec.n[(size_t)level] = *out;
     return HIPEXEC_OK;
 }
 
 int level_end(hipexec *h, LevelRun &run)
 {
-    if (run.pred) {
-        // the counts the kernels produced come back with the call and are compared then (call_end)
+    if (run.sized) {
+        // the counts the kernels produced come back with the call and are compared with the launches then (call_end)
         HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)run.slot * LV_PER, h->d_lvl + (size_t)run.slot * LV_PER, LV_PER * sizeof(uint32_t),
                               hipMemcpyDeviceToHost, h->stream));
-        h->checks.push_back(LevelCheck{run.slot, run.rec.key});
-    } else if (run.slot >= 0 && h->predict) {
-        for (size_t i = 0; i < h->preds.size(); i++) if (h->preds[i].key == run.rec.key) { h->preds.erase(h->preds.begin() + (long)i); break; }
-        if (h->preds.size() >= 64) h->preds.erase(h->preds.begin());
-        h->preds.push_back(run.rec);
-        // test hook: a wrong remembered size, so that the check of call_end and the repeat of the frame can be exercised
-        if (h->predict_spoil && h->preds.back().n.size() > 1 && (int64_t)h->preds.back().n[1] + h->predict_spoil > 0)
-            h->preds.back().n[1] = (uint32_t)((int64_t)h->preds.back().n[1] + h->predict_spoil);
+        h->checks.push_back(LevelCheck{run.slot, run.key, run.launched});
     }
     return HIPEXEC_OK;
 }
@@ -1149,12 +1243,14 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
         }
         HIPCHK(hipEventRecord(h->ev_lit[level & 1], side_s));
         if (!spawn) break;
-        uint32_t nn = 0;
-        CHK(level_count(h, run, level + 1, &nn));
+        uint32_t nn = 0; bool counted = false;
+        CHK(level_count(h, run, level + 1, n, &nn, &counted));
         if (nn == 0) break;
-        h->acc.rays_bounce += nn;
-        h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
-        h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
+        if (counted) {
+            h->acc.rays_bounce += nn;
+            h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
+            h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
+        }
         cur_rays = ray_buf[(level + 1) & 1];
         cur_hits = hit_buf[(level + 1) & 1];
         if (use_tail(h, nn, level + 1, depth)) {
@@ -1227,12 +1323,14 @@ int trace_levels_run(hipexec *h, uint32_t n0, size_t stride, int max_depth, int 
             LAUNCH(HIPEXEC_K_SHADE, (k_shade<MODE>), blocks_for(n), S, cur_rays, cur_hits, n, h->occl.as<uint32_t>(),
                    h->lamp_words, local_level, spawn, next_rays, next_count, n_dev);
         if (!spawn) break;
-        uint32_t nn = 0;
-        CHK(level_count(h, run, level + 1, &nn));
+        uint32_t nn = 0; bool counted = false;
+        CHK(level_count(h, run, level + 1, n, &nn, &counted));
         if (nn == 0) break;
-        h->acc.rays_bounce += nn;
-        h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
-        h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
+        if (counted) {
+            h->acc.rays_bounce += nn;
+            h->acc.tests_tri_closest += (uint64_t)nn * S.n_tri;
+            h->acc.tests_sph_closest += (uint64_t)nn * S.n_sph;
+        }
         if (use_tail(h, nn, level + 1, depth)) {
             CHK(launch_tail<MODE>(h, next_rays, nn, level + 1, depth, stride, level_fill(h, run, level + 1)));
             *levels_used = depth + 1;
@@ -1362,7 +1460,7 @@ int more_lanes(hipexec *h, int want)
         g->is_helper = true; g->device = h->device;
         g->worker = new (std::nothrow) LaneWorker();
         if (!g->worker) return fail(HIPEXEC_E_NOMEM, "out of host memory");
-        g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words;
+        g->S = h->S; g->B = h->B; g->bvh_ok = true; g->lamp_words = h->lamp_words; g->pred_home = h->pred_home;
         CHK(create_lane_resources(g, h->S.n_lamp));
         HIPCHK(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
     }
@@ -1390,7 +1488,8 @@ int render_dispatch(hipexec *h, const hipexec_render_cfg *c, float4 *d_rgba, int
         hipexec *g = h->helpers[(size_t)k - 1];
         g->win_lo = h->win_lo; g->win_hi = h->win_hi;
         for (int q = 0; q < 4; q++) g->rect[q] = h->rect[q];
-        g->predict_now = h->predict_now;
+        g->size_mode = h->size_mode;
+        memcpy(g->S.cam_pos, h->S.cam_pos, sizeof g->S.cam_pos); memcpy(g->S.cam_mat, h->S.cam_mat, sizeof g->S.cam_mat);
         g->block64_below = h->block64_below;
         g->refill_closest = h->refill_closest; g->sched_w = h->sched_w; g->closest_per_block = h->closest_per_block;
         g->bvh_refill = h->bvh_refill; g->shadow_waves6_from = h->shadow_waves6_from; g->bvh_default = true; g->overlap_levels = h->overlap_levels;
@@ -1490,7 +1589,8 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     CHK(pool_alloc(h->device, false, CNT64_WORDS * sizeof(unsigned long long), (void **)&h->d_cnt64));
     CHK(pool_alloc(h->device, false, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), (void **)&h->d_lvl));
     CHK(pool_alloc(h->device, true, (size_t)LV_SLOTS * LV_PER * sizeof(uint32_t), (void **)&h->h_lvl));
-    if (const char *e = knob("HIPEXEC_PREDICT")) h->predict = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_PREDICT")) { const int v = atoi(e); h->size_default = v == 0 ? SIZE_WAIT : (v == 2 ? SIZE_BOUND : SIZE_AUTO); }
+    h->size_mode = h->size_default;
     if (const char *e = knob("HIPEXEC_PREDICT_SPOIL")) h->predict_spoil = atoi(e);   // test hook, see level_end
     CHK(pool_alloc(h->device, true, h->n_cnt32 * sizeof(uint32_t), (void **)&h->h_cnt32));
     CHK(pool_alloc(h->device, true, CNT64_WORDS * sizeof(unsigned long long), (void **)&h->h_cnt64));
@@ -1500,18 +1600,33 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     return HIPEXEC_OK;
 }
 
-// Runs `frame` (call_begin ... call_end); if one of its batches ran from remembered queue sizes and the kernels
-// produced other sizes (the check of call_end), the frame is traced once more with every size read back.
+// Runs `frame` (call_begin ... call_end); if a level of one of its batches produced more rays than its launch was sized
+// for (the check of call_end), the frame is traced once more with every launch sized from the bound.
 template <class F>
 int run_checked(hipexec *h, F frame)
 {
     int rc = frame();
     if (rc == HIPEXEC_OK && h->redo) {
-        h->redo = false; h->predict_now = false;
+        h->redo = false; h->size_mode = SIZE_BOUND;
         rc = frame();
-        h->predict_now = true; h->redo = false;
+        h->size_mode = h->size_default; h->redo = false;
     }
     return rc;
+}
+
+// executor-level knobs of the environment (honoured only with HIPEXEC_KNOBS=1, see knob)
+void read_executor_knobs(hipexec *h, bool *anyhit_lds_set)
+{
+    if (const char *e = knob("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
+    if (const char *e = knob("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
+    if (const char *e = knob("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_ANYHIT_LDS")) { h->anyhit_lds = atoi(e) != 0; *anyhit_lds_set = true; }
+    if (const char *e = knob("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
+    if (const char *e = knob("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = knob("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
+    if (const char *e = knob("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
+    if (const char *e = knob("HIPEXEC_LANES")) h->max_lanes = std::max(1, std::min(8, atoi(e)));      // 1: no further lanes
 }
 
 }  // namespace
@@ -1542,26 +1657,20 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
     int rc = [&]() -> int {
         StageTrace st; g_stage = &st;
         struct Unset { ~Unset() { g_stage = nullptr; } } unset;
+        h->share = new (std::nothrow) SceneShare();
+        if (!h->share) return fail(HIPEXEC_E_NOMEM, "out of host memory");
+        h->share->device = device; h->pred_home = h->share;
         CHK(static_scratch_init(device));
         CHK(create_lane_resources(h, scene->n_lamp));
         STAGE("lane resources");
-        if (const char *e = knob("HIPEXEC_CLOSEST_R")) h->closest_r = atoi(e);
-        if (const char *e = knob("HIPEXEC_ANYHIT_R")) h->anyhit_r = atoi(e);
-        if (const char *e = knob("HIPEXEC_CLOSEST_LDS")) h->closest_lds = atoi(e) != 0;
         bool anyhit_lds_set = false;
-        if (const char *e = knob("HIPEXEC_ANYHIT_LDS")) { h->anyhit_lds = atoi(e) != 0; anyhit_lds_set = true; }
-        if (const char *e = knob("HIPEXEC_ALGO")) h->bvh_default = strcmp(e, "scan") != 0;
-        if (const char *e = knob("HIPEXEC_BVH_REFILL")) h->bvh_refill = atoi(e) != 0;
-        if (const char *e = knob("HIPEXEC_REFILL_CLOSEST")) h->refill_closest = std::max(1, std::min(64, atoi(e)));
-        if (const char *e = knob("HIPEXEC_CLOSEST_PER_BLOCK")) h->closest_per_block = std::max(256, std::min(16384, atoi(e)));
-        if (const char *e = knob("HIPEXEC_SCHED_W")) h->sched_w = std::max(0, std::min(255, atoi(e)));
+        read_executor_knobs(h, &anyhit_lds_set);
         CHK(build_scene(h, scene));
         STAGE("rest of the scene");
         if (!h->bvh_default || !h->bvh_ok) CHK(ensure_scan_records(h));       // the scans are this executor's algorithm
         // full scans stage the lamp records through LDS (measured faster); with chunk culling each
         // wave reads only the chunks it needs and the scalar path wins
         if (!anyhit_lds_set) h->anyhit_lds = h->S.cull == 0;
-        if (const char *e = knob("HIPEXEC_LANES")) h->max_lanes = std::max(1, std::min(8, atoi(e)));      // 1: no further lanes
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         // (further lanes are made by the first frame that uses them, see more_lanes: streams are bound to the
         // process's few hardware queues in the order they are created, and an executor that is used with one lane,
@@ -1570,6 +1679,48 @@ int hipexec_create(hipexec_t **out, const hipexec_scene_desc *scene, int device)
     }();
     if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
     *out = h;
+    return HIPEXEC_OK;
+}
+
+int hipexec_clone(hipexec_t **out, hipexec_t *src)
+{
+    if (!out) return fail(HIPEXEC_E_INVALID, "out handle pointer is NULL");
+    *out = nullptr;
+    if (!src || !src->share) return fail(HIPEXEC_E_INVALID, "source handle is NULL");
+    HIPCHK(hipSetDevice(src->device));
+    hipexec *h = new (std::nothrow) hipexec();
+    if (!h) return fail(HIPEXEC_E_NOMEM, "out of host memory");
+    h->device = src->device;
+    src->share->refs.fetch_add(1, std::memory_order_relaxed);
+    h->share = src->share; h->pred_home = src->share;
+    int rc = [&]() -> int {
+        CHK(create_lane_resources(h, src->S.n_lamp));
+        bool anyhit_lds_set = false;
+        read_executor_knobs(h, &anyhit_lds_set);
+        // the scene, the hierarchy and the source's settings; the camera-dependent scan records stay the source's own
+        h->S = src->S; h->B = src->B; h->bvh_ok = src->bvh_ok; h->lamp_words = src->lamp_words;
+        h->S.tri_primx = nullptr; h->S.pair_cam = nullptr; h->scan_ready = false;
+        h->bvh_default = src->bvh_default; h->max_lanes = src->max_lanes;
+        h->anyhit_lds = anyhit_lds_set ? h->anyhit_lds : src->anyhit_lds;
+        if (!h->bvh_default || !h->bvh_ok) CHK(ensure_scan_records(h));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        return HIPEXEC_OK;
+    }();
+    if (rc != HIPEXEC_OK) { hipexec_destroy(h); return rc; }
+    *out = h;
+    return HIPEXEC_OK;
+}
+
+int hipexec_set_camera(hipexec_t *h, const float *cam_pos, const float *cam_mat)
+{
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (!cam_pos || !cam_mat) return fail(HIPEXEC_E_INVALID, "cam_pos/cam_mat is NULL");
+    if (h->call_open) CHK(hipexec_sync(h));                 // a frame in flight keeps the camera it was submitted with
+    memcpy(h->S.cam_pos, cam_pos, sizeof h->S.cam_pos); memcpy(h->S.cam_mat, cam_mat, sizeof h->S.cam_mat);
+    // the scans' camera records are made again by the next call that scans (a set-up cost of that call; the hierarchy,
+    // the default algorithm, has nothing that depends on the camera)
+    h->scan_ready = false;
+    if (!h->bvh_default || !h->bvh_ok) { HIPCHK(hipSetDevice(h->device)); CHK(ensure_scan_records(h)); }
     return HIPEXEC_OK;
 }
 
@@ -1585,9 +1736,9 @@ void hipexec_destroy(hipexec_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->side) { (void)hipStreamSynchronize(h->side); pool_stream_back(h->device, h->side); }
     for (hipEvent_t e : {h->ev_hits[0], h->ev_hits[1], h->ev_lit[0], h->ev_lit[1]}) if (e) (void)hipEventDestroy(e);
-    for (void *p : h->scene_allocs) pool_free(h->device, false, p);
+    share_release(h->share); h->share = nullptr;                              // the last executor of the scene frees it
     pool_free(h->device, false, h->build_tmp);
-    for (Buf *b : {&h->rayA, &h->rayB, &h->hit0, &h->hitN, &h->hitM, &h->local, &h->occl, &h->shadowq, &h->out_rgba, &h->out_ids,
+    for (Buf *b : {&h->cam_primx, &h->cam_pairs, &h->rayA, &h->rayB, &h->hit0, &h->hitN, &h->hitM, &h->local, &h->occl, &h->shadowq, &h->out_rgba, &h->out_ids,
                    &h->stage_in, &h->stage_out}) b->release();
     pool_free(h->device, false, h->d_cnt32);
     pool_free(h->device, false, h->d_cnt64);
@@ -1871,6 +2022,11 @@ int hipexec_any_hits_static(hipexec_t *h, int mode, const float *d_rays6, uint32
         return fail(HIPEXEC_E_LIMIT, "%u rays exceed the %u of the fixed work memory (HIPEXEC_STATIC_MAX_RAYS)", n, HIPEXEC_STATIC_MAX_RAYS);
     unsigned char *base = (h->device >= 0 && h->device < STATIC_MAX_DEVICES) ? g_static_ptr[h->device] : nullptr;
     if (!base) return fail(HIPEXEC_E_DEVICE, "no fixed work memory on device %d", h->device);
+    // everything that can refuse the call comes before the first enqueue: a refused call leaves the shared array alone
+    const bool bvh = h->bvh_default && h->bvh_ok;
+    if (!bvh && !h->scan_ready)
+        return fail(HIPEXEC_E_INVALID, "the scan algorithm's records do not exist yet and this call cannot allocate them: run any other "
+                                       "call of this executor with the scan algorithm first");
     HIPCHK(hipSetDevice(h->device));
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(base);
     float4 *recs = reinterpret_cast<float4 *>(base + STATIC_CNT_BYTES);
@@ -1882,10 +2038,6 @@ int hipexec_any_hits_static(hipexec_t *h, int mode, const float *d_rays6, uint32
     const dim3 blk(256), grid(blocks_for(n));
     hipLaunchKernelGGL(k_import_rays, grid, blk, 0, st, d_rays6, n, recs);
     HIPCHK(hipGetLastError());
-    const bool bvh = h->bvh_default && h->bvh_ok;
-    if (!bvh && !h->scan_ready)
-        return fail(HIPEXEC_E_INVALID, "the scan algorithm's records do not exist yet and this call cannot allocate them: run any other "
-                                       "call of this executor with the scan algorithm first");
     if (bvh) {
         if (mode == HIPEXEC_MODE_CL) hipLaunchKernelGGL((k_bvh_anyhit<HIPEXEC_MODE_CL>), grid, blk, 0, st, h->S, h->B, recs, n, bits, 1u, cnt);
         else hipLaunchKernelGGL((k_bvh_anyhit<HIPEXEC_MODE_CPU>), grid, blk, 0, st, h->S, h->B, recs, n, bits, 1u, cnt);
@@ -1912,7 +2064,7 @@ int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6
     if (n == 0) { if (stats) memset(stats, 0, sizeof *stats); return HIPEXEC_OK; }
     if (!rays6 || !colours3) return fail(HIPEXEC_E_INVALID, "rays6/colours3 is NULL");
     CHK(call_begin(h, false, 0));
-    h->predict_now = false;                       // the rays of a batch call are the caller's: no remembered queue sizes apply
+    h->size_mode = SIZE_WAIT;                     // a synchronous call on the caller's rays: the counts are read back level by level
     const std::array<int64_t, 24> no_key{};
     int rc = [&]() -> int {
     const DScene &S = h->S;
@@ -1942,7 +2094,7 @@ int hipexec_trace_rays(hipexec_t *h, int mode, int max_depth, const float *rays6
     }
     return call_end(h, stats);
     }();
-    h->predict_now = true;
+    h->size_mode = h->size_default;
     return rc;
 }
 

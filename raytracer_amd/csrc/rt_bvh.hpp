@@ -336,10 +336,15 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
 // Both are used with margin: A = BVH_LOOSE * max |e1||e2| over the subtree, and the tight form
 // with BVH_TIGHT when the normals of the subtree lie in a cone that keeps s*c >= 2e-3 for this
 // ray (g below is a lower bound of s*c / BVH_TIGHT).  E covers the rounding of the slab
-// arithmetic itself (each face moves by less than 2^-22 of |o| + |box coordinate|).  The
-// slab terms are formed as ((face - in) - o) * inv, never as face*inv - o*inv: with a zero
-// direction component inv is +-inf and only the first form keeps the sign of (face - o), so
-// that an origin between the two faces gives (-inf, +inf) on that axis.
+// arithmetic itself (each face moves by less than 2^-22 of |o| + |box coordinate|).  Boxes
+// are stored as centre c and half extent h >= 0, and the two faces of an axis are evaluated
+// as fma(-+(h + infl), |inv|, (c - o) * inv) (bvh_box).  What keeps that conservative when a
+// direction component is (nearly) zero: an infinite inv makes every term of the axis +-inf or
+// NaN, and a NaN drops out of the max3 / min3, so the axis merely stops culling; a huge
+// finite inv would let (c - o) * inv overflow while the half-extent term stays finite (an
+// empty interval for a box the ray is inside of), so tray_make clamps |inv| to inv_clamp, a
+// value that every product with |c - o| <= Q survives and that still reaches past every
+// parameter at which a hit can be accepted (inv_clamp * |d| >= 6e6, see build_bvh).
 struct TRay { f3 o, inv, dhat; float dlen, E; };
 
 DEV TRay tray_make(const DScene &S, const DBvh &B, f3 o, f3 d) {

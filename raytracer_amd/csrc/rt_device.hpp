@@ -63,7 +63,7 @@ struct PairCam {
 // every direction with |d.x| > 1e-30 (the rest merely take the exact path, which rejects).
 // The same record layout, without the sign factor s and with q taken from a lamp instead of
 // the camera, serves shadow rays (all shadow rays of a lamp lie on lines through the lamp).
-// FILTER record of a pair of triangles for arbitrary rays (see k_setup_pairs)
+// FILTER record of a pair of triangles for arbitrary rays (see k_setup_gen_pairs)
 struct PairGen {
     v2f ud[3], um[3];    // u = dot(ud, d) + dot(um, mo)
     v2f vd[3], vm[3];    // v = dot(vd, d) + dot(vm, mo)

@@ -80,30 +80,28 @@ __global__ void k_setup_exact(uint32_t n_tri, uint32_t n_pad, const float *tp, c
         f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
         f3 e1 = mk(te1[3 * i], te1[3 * i + 1], te1[3 * i + 2]);
         f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
-        f3 c21 = cross(e2, e1);                      // the same operations as in k_setup_pairs
+        f3 c21 = cross(e2, e1);                      // the same operations as in k_setup_cam_pairs
         r0 = make_float4(p.x, p.y, p.z, c21.x); r1 = make_float4(e1.x, e1.y, e1.z, c21.y); r2 = make_float4(e2.x, e2.y, e2.z, c21.z);
     }
     tri_exact[3 * (size_t)i] = r0; tri_exact[3 * (size_t)i + 1] = r1; tri_exact[3 * (size_t)i + 2] = r2;
 }
 
-// One thread per pair of triangles (2j, 2j+1).  `rmax` bounds the distance of ray origins
-// from `center` the general FILTER slack is valid for (farther origins scale their threshold).
-__global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,
-                              f3 cam, f3 center, float rmax, float4 *tri_exact, float4 *tri_primx,
-                              PairCam *pair_cam, PairGen *pair_gen)
+// Camera-dependent records of the index-order scans, one thread per pair of triangles (2j, 2j+1): the EXACT
+// camera-ray records (what depends only on camera and triangle of the exact test, from the same operations) and the
+// FILTER pair records of the camera rays.  Made per executor and again when its camera changes.
+__global__ void k_setup_cam_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,
+                                  f3 cam, float4 *tri_primx, PairCam *pair_cam)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * j >= n_pad) return;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    PairCam pc; PairGen pg;
+    PairCam pc;
     for (int h = 0; h < 2; h++) {
         uint32_t i = 2 * j + h;
         f3 zero = mk(0.f, 0.f, 0.f);
         // default: never passes (padding, zero-area triangles)
         f3 cu = mk(FILTER_NEVER, 0.f, 0.f), cv = mk(-FILTER_NEVER, 0.f, 0.f), cw = zero;
-        f3 ud = mk(FILTER_NEVER, 0.f, 0.f), um = zero, vd = mk(-FILTER_NEVER, 0.f, 0.f), vm = zero, wd = zero, wm = zero;
         if (i >= n_tri) {
-            tri_exact[3 * i] = z; tri_exact[3 * i + 1] = z; tri_exact[3 * i + 2] = z;
             tri_primx[3 * i] = z; tri_primx[3 * i + 1] = z; tri_primx[3 * i + 2] = z;
         } else {
             f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
@@ -111,9 +109,6 @@ __global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, c
             f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
             // EXACT: same operations as the per-ray code of the reference
             f3 c21 = cross(e2, e1);
-            tri_exact[3 * i] = make_float4(p.x, p.y, p.z, c21.x);
-            tri_exact[3 * i + 1] = make_float4(e1.x, e1.y, e1.z, c21.y);
-            tri_exact[3 * i + 2] = make_float4(e2.x, e2.y, e2.z, c21.z);
             f3 q = cam - p;
             float dett = dot(q, cross(e1, e2));
             f3 ceq = cross(e2, q);
@@ -122,14 +117,9 @@ __global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, c
             tri_primx[3 * i + 1] = make_float4(ceq.x, ceq.y, ceq.z, 0.f);
             tri_primx[3 * i + 2] = make_float4(cqe.x, cqe.y, cqe.z, 0.f);
             float nc = sqrtf(dot(c21, c21)), nu = sqrtf(dot(ceq, ceq)), nv = sqrtf(dot(cqe, cqe));
-            f3 pp = p - center;
-            float ne = sqrtf(dot(e1, e1)) + sqrtf(dot(e2, e2));
             float slack_c = FILTER_KAPPA * (nc + nu + nv);
-            float slack_g = FILTER_KAPPA * (ne * (rmax + sqrtf(dot(pp, pp))) + nc);
-            bool finite = (slack_c < 3.0e38f) && (slack_g < 3.0e38f);
-            if (!finite) {
-                // let the exact test decide: all-zero records always pass
-                cu = zero; cv = zero; ud = zero; vd = zero;
+            if (!(slack_c < 3.0e38f)) {
+                cu = zero; cv = zero;                 // let the exact test decide: all-zero records always pass
             } else if (nc > 0.f) {
                 // camera rays: a hit needs t = dett/det > 0, i.e. sign(det) = sign(dett) = s; with
                 // everything multiplied by s the three edge functions must be >= 0 (up to slack)
@@ -138,8 +128,41 @@ __global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, c
                     float k = s / slack_c;
                     cu = ceq * k; cv = cqe * k; cw = ((c21 - ceq) - cqe) * k;
                 }
-                // arbitrary rays, coordinates translated by -center: with o' = o - center,
-                // mo = cross(o', d), p' = p - center, k1 = cross(p', e1), k2 = cross(e2, p'):
+            }
+            // nc == 0: det == 0 for every ray, the exact tests always reject -> never passes
+        }
+        set_cam_half(pc, h, cu, cv, cw);
+    }
+    pair_cam[j] = pc;
+}
+
+// FILTER pair records for arbitrary rays, one thread per pair of triangles (2j, 2j+1).  `rmax` bounds the distance of
+// ray origins from `center` the slack is valid for (farther origins scale their threshold).  Camera independent:
+// shared by every executor of the scene.
+__global__ void k_setup_gen_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, const float *te1, const float *te2,
+                                  f3 center, float rmax, PairGen *pair_gen)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * j >= n_pad) return;
+    PairGen pg;
+    for (int h = 0; h < 2; h++) {
+        uint32_t i = 2 * j + h;
+        f3 zero = mk(0.f, 0.f, 0.f);
+        f3 ud = mk(FILTER_NEVER, 0.f, 0.f), um = zero, vd = mk(-FILTER_NEVER, 0.f, 0.f), vm = zero, wd = zero, wm = zero;
+        if (i < n_tri) {
+            f3 p = mk(tp[3 * i], tp[3 * i + 1], tp[3 * i + 2]);
+            f3 e1 = mk(te1[3 * i], te1[3 * i + 1], te1[3 * i + 2]);
+            f3 e2 = mk(te2[3 * i], te2[3 * i + 1], te2[3 * i + 2]);
+            f3 c21 = cross(e2, e1);
+            float nc = sqrtf(dot(c21, c21));
+            f3 pp = p - center;
+            float ne = sqrtf(dot(e1, e1)) + sqrtf(dot(e2, e2));
+            float slack_g = FILTER_KAPPA * (ne * (rmax + sqrtf(dot(pp, pp))) + nc);
+            if (!(slack_g < 3.0e38f)) {
+                ud = zero; vd = zero;                 // let the exact test decide
+            } else if (nc > 0.f) {
+                // coordinates translated by -center: with o' = o - center, mo = cross(o', d), p' = p - center,
+                // k1 = cross(p', e1), k2 = cross(e2, p'):
                 //   detu = dot(e2, mo) - dot(d, k2)
                 //   detv = -dot(e1, mo) - dot(d, k1)
                 //   w    = det - detu - detv = dot(d, c21 + k2 + k1) + dot(e1 - e2, mo)
@@ -149,9 +172,7 @@ __global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, c
                 vd = (-k1) * g; vm = (-e1) * g;
                 wd = ((c21 + k2) + k1) * g; wm = (e1 - e2) * g;
             }
-            // nc == 0: det == 0 for every ray, the exact tests always reject -> never passes
         }
-        set_cam_half(pc, h, cu, cv, cw);
         set_half(pg.ud[0], h, ud.x); set_half(pg.ud[1], h, ud.y); set_half(pg.ud[2], h, ud.z);
         set_half(pg.um[0], h, um.x); set_half(pg.um[1], h, um.y); set_half(pg.um[2], h, um.z);
         set_half(pg.vd[0], h, vd.x); set_half(pg.vd[1], h, vd.y); set_half(pg.vd[2], h, vd.z);
@@ -159,7 +180,6 @@ __global__ void k_setup_pairs(uint32_t n_tri, uint32_t n_pad, const float *tp, c
         set_half(pg.wd[0], h, wd.x); set_half(pg.wd[1], h, wd.y); set_half(pg.wd[2], h, wd.z);
         set_half(pg.wm[0], h, wm.x); set_half(pg.wm[1], h, wm.y); set_half(pg.wm[2], h, wm.z);
     }
-    pair_cam[j] = pc;
     pair_gen[j] = pg;
 }
 

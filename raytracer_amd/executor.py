@@ -29,13 +29,26 @@ def n_tiles(height: int, tile_first: int = 0, tile_step: int = 1) -> int:
 
 
 class HipExecutor:
-    def __init__(self, scene: FlatScene, device: int = -1):
+    def __init__(self, scene: FlatScene, device: int = -1, _clone_of: "HipExecutor | None" = None):
         self._lib = _abi.load_library()
         self.scene = scene
-        desc, keep = scene.to_desc()
         self._h = C.c_void_p()
+        if _clone_of is not None:
+            self._check(self._lib.hipexec_clone(C.byref(self._h), _clone_of._h))
+            return
+        desc, keep = scene.to_desc()
         self._check(self._lib.hipexec_create(C.byref(self._h), C.byref(desc), int(device)))
         del keep
+
+    def clone(self) -> "HipExecutor":
+        """A further executor of the same scene that shares this one's device copy of it (hipexec_clone)."""
+        return HipExecutor(self.scene, _clone_of=self)
+
+    def set_camera(self, cam_pos, cam_mat):
+        """Camera of later calls: position [3] and matrix [3][3] (rows = JSON transform rows)."""
+        p = np.ascontiguousarray(cam_pos, dtype=np.float32).reshape(3)
+        m = np.ascontiguousarray(cam_mat, dtype=np.float32).reshape(9)
+        self._check(self._lib.hipexec_set_camera(self._h, p.ctypes.data_as(C.POINTER(C.c_float)), m.ctypes.data_as(C.POINTER(C.c_float))))
 
     # -- plumbing -------------------------------------------------------------------------
     def _check(self, rc):
@@ -188,7 +201,8 @@ def trim(device: int = -1):
 
 
 class FramesInFlight:
-    """Throughput mode: `depth` executors of one scene, one lane each, take device-resident frames in turn.
+    """Throughput mode: `depth` executors of one scene (one uploaded, the others its clones: they share the scene's device
+    memory), one lane each, take device-resident frames in turn.
 
     submit() enqueues a frame (asynchronous) on the next executor and returns the slot it used; collect(slot) waits
     for that frame and returns its Stats.  A slot must be collected before submit() reaches it again; submit() does it
@@ -196,7 +210,8 @@ class FramesInFlight:
     camera and first-bounce launches of the next.  The frames are the ones a single executor renders, bit for bit."""
 
     def __init__(self, scene: FlatScene, device: int = -1, depth: int = 2, lanes: int | None = None):
-        self.ex = [HipExecutor(scene, device=device) for _ in range(depth)]
+        first = HipExecutor(scene, device=device)
+        self.ex = [first] + [first.clone() for _ in range(depth - 1)]      # one device copy of the scene for all of them
         for e in self.ex:
             e.set_lanes(lanes if lanes else (1 if depth > 1 else 2))
         self.stats = [_abi.Stats() for _ in range(depth)]

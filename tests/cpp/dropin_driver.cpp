@@ -90,11 +90,11 @@ int main(int argc, char **argv)
         for (int i = 0; i < nr[0]; i++) rays.push_back(RayData(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2], rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5]));
         image_bitmap full(W, H), blocks(W, H);
         renderSceneCl(full, scene);
-        // the block walk of ray_tracer_cl.cpp:15-55 with 48x48 blocks, through renderSubBlockCl
+        // the block walk of ray_tracer_cl.cpp:15-55 with SUB_BLOCK_WIDTH x SUB_BLOCK_HEIGHT (48x48) blocks, through renderSubBlockCl
         extern std::shared_ptr<OpenClExecutor> makeExecutorForTest(const Scene &);
         auto ex = makeExecutorForTest(scene);
-        for (int y = 0; y < H; y += 48) for (int x = 0; x < W; x += 48)
-            renderSubBlockCl(blocks, scene, ex, x, y, std::min(48, W - x), std::min(48, H - y), W, H);
+        for (int y = 0; y < H; y += SUB_BLOCK_HEIGHT) for (int x = 0; x < W; x += SUB_BLOCK_WIDTH)
+            renderSubBlockCl(blocks, scene, ex, x, y, std::min(SUB_BLOCK_WIDTH, W - x), std::min(SUB_BLOCK_HEIGHT, H - y), W, H);
         std::vector<Hit> hits;
         computeClosestHitsCl(scene, ex, rays, hits);
         std::vector<char> occ(rays.size(), 0);

@@ -42,6 +42,15 @@ public:
     void setScaleY(float v) { scaleY = v; }
 };
 
+#ifdef RT_USE_REFERENCE_STANDALONE_HEADERS
+// Build container only (-I/root/reference): the two headers of the reference that compile on their own take the place
+// of their stand-ins, so the drop-in source meets the real image_bitmap interface (getWidth / getHeight / getRawData /
+// setPixel, image_bitmap.h:11-75) and the real block size (config.h:17-18).  Only the glm-dependent types below stay mocked.
+#include "config.h"
+#include "image_bitmap.h"
+#else
+#define SUB_BLOCK_WIDTH (48)
+#define SUB_BLOCK_HEIGHT (48)
 class image_bitmap {
     std::vector<float> d; int W, H;
 public:
@@ -63,6 +72,8 @@ public:
             }
     }
 };
+
+#endif
 
 class OpenClExecutor;
 

@@ -367,18 +367,19 @@ def test_sub_rectangles_equal_the_frame_and_the_oracle(backends, mode, depth):
                                               walk.ctypes.data, None, None))
 
 
-@pytest.mark.parametrize("spoil", ["0", "64", "-64", "off"])
+@pytest.mark.parametrize("spoil", ["0", "64", "-64", "off", "bound"])
 def test_remembered_queue_sizes(monkeypatch, spoil):
-    """From the second frame of a configuration on, the launches of the recursion levels are sized from the queue
-    sizes the first frame produced, without waiting for counts, and the produced counts are checked when the call is
-    collected.  HIPEXEC_PREDICT_SPOIL stores wrong sizes (too large / too small): the check must catch it and the frame
-    must come out right all the same; HIPEXEC_PREDICT=0 always waits.  Synchronous, sharded and asynchronous
-    (device-resident) frames against the oracle, three frames each."""
+    """The launches of the recursion levels are sized on the host: from the bound n(L+1) <= n(L) in the first frame of a
+    configuration, from the queue sizes the last frame produced afterwards, never waiting for a count; the produced
+    counts are checked when the call is collected.  HIPEXEC_PREDICT_SPOIL stores wrong sizes: too large is harmless,
+    too small loses rays on the device, which the check must catch (the frame is then traced again from the bound);
+    the frame must come out right all the same.  HIPEXEC_PREDICT=0 always waits for the counts, =2 always sizes from
+    the bound.  Synchronous, sharded and asynchronous (device-resident) frames against the oracle, three frames each."""
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
     from tests.util import HipMem
-    if spoil == "off":
-        monkeypatch.setenv("HIPEXEC_PREDICT", "0")
+    if spoil in ("off", "bound"):
+        monkeypatch.setenv("HIPEXEC_PREDICT", "0" if spoil == "off" else "2")
     else:
         monkeypatch.setenv("HIPEXEC_PREDICT_SPOIL", spoil)
     fs = scenegen.small_variant("mirror").to_flat()

@@ -1,7 +1,7 @@
 """hipexec_any_hits_static (device pointers, the library's fixed work memory, no allocation) against
-hipexec_any_hits on the same rays: identical occlusion flags, on two calls in a row, the second with a
-smaller input (the fixed array keeps the first call's contents), for both algorithms and both rule sets,
-plus the size limit.  Device memory for the rays and flags is the test's own (plain hipMalloc)."""
+hipexec_any_hits and against the CPU oracle on the same rays: identical occlusion flags, on two calls in a
+row, the second with a smaller input (the fixed array keeps the first call's contents), for both algorithms
+and both rule sets, plus the size limit and the free device memory before and after a call.  Device memory for the rays and flags is the test's own (plain hipMalloc)."""
 import numpy as np
 import pytest
 
@@ -38,8 +38,10 @@ def _static(ex, hip, d_rays, d_hits, rays, pre, mode):
 @pytest.mark.parametrize("mode", [CPU, CL])
 def test_static_any_hits_equals_any_hits_twice(mode, algo):
     from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
     hip = _Hip()
     fs = scenegen.small_variant("c2").to_flat()
+    orc = Oracle(fs)
     n1, n2 = 70001, 4099                          # neither a multiple of the block size; second call smaller
     d_rays, d_hits = hip.malloc(n1 * 24), hip.malloc(n1)
     try:
@@ -49,8 +51,12 @@ def test_static_any_hits_equals_any_hits_twice(mode, algo):
                 rays = _rays(n, seed)
                 pre = (np.arange(n) % 5 == 0).astype(np.int8)
                 want = ex.any_hits(rays, mode, hits=pre.copy())
+                ref = orc.any_hits(rays, mode, hits=pre.copy())
+                free_before = hip.mem_free()
                 got = _static(ex, hip, d_rays, d_hits, rays, pre, mode)
+                assert hip.mem_free() == free_before, "the call changed the free device memory"
                 assert 0 < int(want.sum()) < n
+                assert np.array_equal(got, ref), f"{algo} mode {mode}: {(got != ref).sum()} of {n} flags differ from the oracle's"
                 assert np.array_equal(got, want), f"{algo} mode {mode}: {(got != want).sum()} of {n} flags differ"
     finally:
         hip.free(d_rays); hip.free(d_hits)

@@ -67,3 +67,9 @@ class HipMem:
 
     def sync(self):
         assert self.lib.hipDeviceSynchronize() == 0
+
+    def mem_free(self):
+        """Free device memory in bytes (hipMemGetInfo)."""
+        free, total = self.C.c_size_t(), self.C.c_size_t()
+        assert self.lib.hipMemGetInfo(self.C.byref(free), self.C.byref(total)) == 0
+        return free.value
