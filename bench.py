@@ -7,9 +7,16 @@ through torch.distributed.run) the frame is split into interleaved 8-row tiles, 
 its tiles, and the tiles are gathered to rank 0 over RCCL inside the timed region; total work is
 fixed, so scaling is "strong".
 
+`value` is the rate of a render loop that keeps K frames in flight (K executors of ONE device copy of the scene take the
+frames in turn; every frame is traced completely and gathered); the line also carries `single_frame_ms` (one frame at a
+time), `first_frame_ms` (a frame whose launches are sized from bounds only, as the first frame of a configuration is) and
+`moving_camera` (the same loop with a new camera every frame).
+
 Prints ONE JSON line on rank 0 with the whole-job rate and, at N = 1:
   roofline        the dominant kernel class of the default algorithm (hierarchy traversal): FLOP the kernel
-                  executed (counted on the device) / its HIP-event time / vector-FP32 peak;
+                  executed (counted on the device) / its HIP-event time in frames rendered ONE AT A TIME on one stream
+                  (launches that do not overlap) / vector-FP32 peak; the figures of the overlapped launches of the timed
+                  region are kept beside it under `overlapped`;
   roofline_brute  the same frame traced by the reference's own algorithm (every ray against every triangle,
                   index order), 1 warm-up + 2 frames: executed packed-FP32 instructions / event time / peak;
   cpu_baseline    the CPU oracle (restatement of ray_tracer.cpp) on a bounded sample of the same frame, one
@@ -108,7 +115,7 @@ def pmc_quote(kernel_class, workload, algo):
     for name, m in summ.items():
         if not name.startswith("rt::" + kernel_class + "<"):
             continue
-        c = m.get("counters", {})
+        c = m.get("counters_per_frame") or m.get("counters", {})      # ratios below: any common normalisation cancels
         q = {"source": os.path.relpath(files[-1], ROOT), "kernel": name}
         for k in ("l2_hit_rate", "occupancy_waves_per_simd"):
             if k in m:
@@ -126,8 +133,11 @@ def pmc_quote(kernel_class, workload, algo):
             q["live_lane_fraction"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
         if c.get("SQ_WAVE_CYCLES"):
             q["wait_fraction_of_wave_cycles"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
-        if m.get("launches_per_frame") and "hbm_read_bytes_corrected" in m and "hbm_write_bytes" in m:
-            q["hbm_bytes_per_launch"] = (m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]) / m["launches_per_frame"]
+        if "hbm_bytes_per_launch" in m:
+            q["hbm_bytes_per_launch"] = m["hbm_bytes_per_launch"]
+        for k in ("l2_miss_bytes_per_launch", "avg_launch_ms_serial", "valu_insts_per_wave"):
+            if k in m:
+                q[k] = m[k]
         return q
     return None
 
@@ -235,6 +245,46 @@ def cpu_baseline(fs, W, H, depth, budget_s=20.0):
 
 
 # ----------------------------------------------------------------------------------------
+# per-rank diagnostics of an N > 1 run
+# ----------------------------------------------------------------------------------------
+class RankDiag:
+    """What one rank spent per frame of the timed region, so that a scaling shortfall can be read off the line: the device
+    time of its share of the frame (the executor's HIP events around the frame's launches), the time this process
+    waited for it in collect, and the gather (events on the stream the collective runs on; on rank 0 that includes the
+    de-interleave copy).  gather() brings every rank's means to rank 0."""
+    FIELDS = ("compute_ms", "host_wait_ms", "gather_ms", "tiles")
+
+    def __init__(self, frames_in_flight, hw_queues):
+        self.sum = [0.0] * len(self.FIELDS)
+        self.frames = 0
+        self.frames_in_flight, self.hw_queues = frames_in_flight, hw_queues
+
+    def add(self, compute_ms, host_wait_ms, gather_ms, tiles):
+        for k, v in enumerate((compute_ms, host_wait_ms, gather_ms, tiles)):
+            self.sum[k] += float(v)
+        self.frames += 1
+
+    def gather(self, rank, world, device):
+        import torch
+        import torch.distributed as dist
+        mine = torch.tensor([float(rank), float(self.frames), float(self.frames_in_flight), float(self.hw_queues)]
+                            + [v / max(1, self.frames) for v in self.sum], dtype=torch.float64, device=device)
+        rows = [mine]
+        if world > 1:
+            rows = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+        if rank != 0:
+            return None
+        out = []
+        for r in rows:
+            v = [float(x) for x in r.cpu()]
+            d = {"rank": int(v[0]), "frames": int(v[1]), "frames_in_flight": int(v[2]), "hw_queues": int(v[3])}
+            d.update({name: v[4 + k] for k, name in enumerate(self.FIELDS)})
+            out.append(d)
+        return out
+
+
+# ----------------------------------------------------------------------------------------
 # functional self-test of the multi-process path on CPU (gloo): no GPU, no executor, no rate
 # ----------------------------------------------------------------------------------------
 def selftest_cpu(args, rank, world):
@@ -242,18 +292,23 @@ def selftest_cpu(args, rank, world):
     the executor that writes each tile's frame index into its rows.  Prints a line marked "selftest": true."""
     import torch
     import torch.distributed as dist
-    from raytracer_amd.dist import gather_frame, local_tiles, max_local_tiles
+    from raytracer_amd.dist import gather_buffer, gather_frame, local_tiles, max_local_tiles
     _, _, W, H, _, desc = WORKLOADS[args.workload]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     tmax = max_local_tiles(H, world)
     out = torch.zeros((tmax * 8, W, 4), dtype=torch.float32)
+    gbuf = gather_buffer(out)
     ok = True
+    diag = RankDiag(1, 1)
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
+        tc = time.perf_counter()
         for j in range(local_tiles(H, rank, world)):
             out[8 * j:8 * j + 8] = float(rank + j * world)
-        frame = gather_frame(out, H)
+        tg = time.perf_counter()
+        frame = gather_frame(out, H, buf=gbuf)
+        diag.add((tg - tc) * 1e3, (tg - tc) * 1e3, (time.perf_counter() - tg) * 1e3, local_tiles(H, rank, world))
         if rank == 0:
             ok = ok and bool(torch.equal(frame[:, 0, 0], (torch.arange(H) // 8).float()))
     elapsed = time.perf_counter() - t0
@@ -261,10 +316,11 @@ def selftest_cpu(args, rank, world):
     t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(seen); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank = diag.gather(rank, world, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({"selftest": True, "ok": ok, "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps,
                           "warmup": args.warmup, "elapsed_s": float(t[0]), "data": "stand-in executor on CPU (gloo): not a measurement",
-                          "config": {"workload": desc}}), flush=True)
+                          "config": {"workload": desc}, "per_rank": per_rank}), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
     return 0 if ok else 1
@@ -287,6 +343,9 @@ def main(argv=None):
     ap.add_argument("--lanes-per-frame", type=int, default=0, help="lanes of each executor (0: 1 with frames in flight, else 2)")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=list(range(0, 9)),
                     help="executors that take the frames in turn (hierarchy algorithm; 1: one executor with two lanes per frame)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="leave out the serial / single-frame / first-frame / moving-camera legs (profiling passes: every frame of the "
+                         "run is then a frame of the timed loop's kind)")
     ap.add_argument("--selftest-cpu", action="store_true", help="functional check of the multi-process path on CPU (gloo), no GPU")
     args = ap.parse_args(argv)
 
@@ -302,7 +361,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from raytracer_amd import _abi, scenegen
-    from raytracer_amd.dist import gather_frame, max_local_tiles
+    from raytracer_amd.dist import gather_buffer, gather_frame, max_local_tiles
     from raytracer_amd.executor import FramesInFlight, HipExecutor
 
     if not torch.cuda.is_available():
@@ -329,25 +388,47 @@ def main(argv=None):
     ex = pipe.ex[0]
     tmax = max_local_tiles(H, world)
     outs = [torch.zeros((tmax * 8, W, 4), dtype=torch.float32, device=dev) for _ in range(in_flight)]
+    gbufs = [gather_buffer(outs[k]) for k in range(in_flight)]       # rank 0's receive buffers, one per slot, made once
     st = _abi.Stats()
     frame = None
+    frames_rendered = {"bvh": 0, "scan": 0}
+    diag = None                               # RankDiag while the timed region runs
 
     gathered = [None] * in_flight             # per slot: event on torch's stream after the gather that last read outs[slot]
+    g_begin = [torch.cuda.Event(enable_timing=True) for _ in range(in_flight)]
+    g_end = [torch.cuda.Event(enable_timing=True) for _ in range(in_flight)]
+    g_pending = []                            # slots whose gather times have not been read yet
 
-    def submit(time_kernels, a=None):
+    def submit(time_kernels, a=None, camera=None):
         k = pipe.next
         if gathered[k] is not None:           # the executor writes outs[k] from its own streams: not before that gather has read it
             gathered[k].synchronize()
             gathered[k] = None
+            drain_gather_times(k)             # the slot's events are about to be recorded again
+        if camera is not None:
+            pipe.ex[k].set_camera(*camera)
+        frames_rendered[a or algo] += 1
         return pipe.submit(W, H, outs[k].data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
                            time_kernels=time_kernels, algo=a or algo)
 
+    def drain_gather_times(only=None):
+        # gather durations of collected frames whose events have completed (torch's stream was synchronised past them)
+        for e in [e for e in g_pending if only is None or e[0] == only]:
+            g_pending.remove(e)
+            if diag is not None:
+                diag.add(e[1], e[2], g_begin[e[0]].elapsed_time(g_end[e[0]]), tmax)
+
     def collect(slot):
         nonlocal frame
+        t_wait = time.perf_counter()
         s = pipe.collect(slot)                       # waits for the frame's kernels (the executor's own streams)
-        frame = gather_frame(outs[slot], H)          # RCCL gather to rank 0 + de-interleave (torch's stream)
-        gathered[slot] = torch.cuda.Event()
-        gathered[slot].record()
+        t_wait = (time.perf_counter() - t_wait) * 1e3
+        g_begin[slot].record()
+        frame = gather_frame(outs[slot], H, buf=gbufs[slot])   # RCCL gather to rank 0 + de-interleave (torch's stream)
+        g_end[slot].record()
+        gathered[slot] = g_end[slot]
+        if diag is not None:
+            g_pending.append((slot, float(s.total_ms), t_wait))
         return s
 
     def step(time_kernels, exe=None, a=None):
@@ -357,10 +438,11 @@ def main(argv=None):
             s = collect(submit(time_kernels, a))
             C.memmove(C.byref(st), C.byref(s), C.sizeof(_abi.Stats))
             return
+        frames_rendered[a or algo] += 1
         exe.render_device(W, H, outs[0].data_ptr(), None, max_depth=depth, tone=True, tile_first=rank, tile_step=world,
                           time_kernels=time_kernels, stats=st, algo=a or algo)
         exe.sync()
-        frame = gather_frame(outs[0], H)
+        frame = gather_frame(outs[0], H, buf=gbufs[0])
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -378,13 +460,12 @@ def main(argv=None):
     # class's launches with events (every timed launch costs two event records on its stream).
     # every executor of the pipeline renders once before anything is timed (its buffers and its remembered queue sizes
     # belong to it): the W warm-up steps, and more where W is smaller than the number of executors
-    for _ in range(max(args.warmup, in_flight)):
+    # (twice through the executors: an executor sizes its launches exactly once two frames of the configuration agreed)
+    for _ in range(max(args.warmup, 2 * in_flight)):
         step(False)
     step(True)
     probe_ms = [float(st.kernel_ms[k]) for k in range(4)]
     dom = max(range(3), key=lambda k: probe_ms[k])
-    probe_exec = executed_flops_bvh(st, dom, fs.n_sph) if algo == "bvh" else executed_flops_scan(st, dom)
-    probe_launches = int(st.launches[dom])
     agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop", "exec_flop_all")}
 
     def account(s):
@@ -394,18 +475,101 @@ def main(argv=None):
         agg["exec_flop_all"] += sum((executed_flops_bvh(s, k, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, k)) for k in range(3))
         agg["equiv_flop"] += ref_flops[dom] if ref_flops is not None else scan_equiv_flops(s, dom, fs.n_sph)
 
-    fence()
-    t0 = time.perf_counter()
-    slots = []
-    for _ in range(args.steps):
-        slots.append(submit([dom]))
-        if len(slots) >= in_flight:
-            account(collect(slots.pop(0)))
-    while slots:
-        account(collect(slots.pop(0)))
-    fence()
-    elapsed = time.perf_counter() - t0
+
+    def timed_loop(n_steps, time_classes, cameras=None, on_stats=None):
+        """n_steps frames submitted in_flight deep, bracketed by fences; -> elapsed seconds."""
+        fence()
+        t_start = time.perf_counter()
+        slots = []
+        for i in range(n_steps):
+            if len(slots) >= in_flight:
+                sk = collect(slots.pop(0))
+                if on_stats:
+                    on_stats(sk)
+            slots.append(submit(time_classes, camera=cameras[i] if cameras else None))
+        while slots:
+            sk = collect(slots.pop(0))
+            if on_stats:
+                on_stats(sk)
+        fence()
+        return time.perf_counter() - t_start
+
+    diag = RankDiag(in_flight, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    elapsed = timed_loop(args.steps, [dom], on_stats=account)
+    drain_gather_times()
+    rank_diag, diag = diag, None
     lanes = int(st.lanes)
+    per_rank = rank_diag.gather(rank, world, dev) if world > 1 else None
+
+    # ------------------------------------------------------------------------------------------------------------
+    # further legs at N = 1 (hierarchy algorithm): what the headline number is not
+    # ------------------------------------------------------------------------------------------------------------
+    extra = {}
+    if world == 1 and algo == "bvh" and not args.no_extra_legs:
+        n_leg = max(3, min(10, args.steps))
+        # (a) frames ONE AT A TIME on one stream of one executor, every launch timed: launches that do not overlap.
+        #     This is what the roofline fraction of a kernel class is priced on.
+        ser = {"ms": [0.0] * 4, "launches": [0] * 4, "flop": [0.0] * 3, "frame_ms": 0.0}
+        e0 = pipe.ex[0]
+        fence()
+        for _ in range(n_leg):
+            frames_rendered["bvh"] += 1
+            e0.render_device(W, H, outs[0].data_ptr(), None, max_depth=depth, tone=True, time_kernels=True, stats=st, algo="bvh")
+            e0.sync()
+            ser["frame_ms"] += float(st.total_ms)
+            for k in range(4):
+                ser["ms"][k] += float(st.kernel_ms[k]); ser["launches"][k] += int(st.launches[k])
+            for k in range(3):
+                ser["flop"][k] += executed_flops_bvh(st, k, fs.n_sph)
+        ser["frames"] = n_leg
+        extra["serial"] = ser
+
+        def wall_per_frame(exe, n):
+            torch.cuda.synchronize(dev)
+            t_a = time.perf_counter()
+            for _ in range(n):
+                frames_rendered["bvh"] += 1
+                exe.render_device(W, H, outs[0].data_ptr(), None, max_depth=depth, tone=True, stats=st, algo="bvh")
+                exe.sync()
+            return (time.perf_counter() - t_a) / n * 1e3
+
+        # (b) one frame at a time the way a single caller gets it: one executor, two lanes (the library's default)
+        two = pipe.ex[0].clone()
+        try:
+            two.set_lanes(2)
+            wall_per_frame(two, 3)
+            extra["single_frame_ms"] = wall_per_frame(two, n_leg)
+        finally:
+            two.close()
+        # (c) a frame none of whose launch sizes is remembered: every level launched for the bound n(L+1) <= n(L), the way
+        #     the first frame of a configuration (or of a new scene) is; the executor's buffers exist (one frame before)
+        os.environ["HIPEXEC_PREDICT"] = "2"
+        try:
+            fresh = pipe.ex[0].clone()
+        finally:
+            os.environ.pop("HIPEXEC_PREDICT", None)
+        try:
+            fresh.set_lanes(2)
+            wall_per_frame(fresh, 1)
+            extra["first_frame_ms"] = wall_per_frame(fresh, n_leg)
+        finally:
+            fresh.close()
+        # (d) the timed loop again with a new camera every frame (a slow orbit and dolly): nothing is carried from frame to
+        #     frame except launch-size estimates, so the rate should be that of the static loop
+        import numpy as np
+        cams = []
+        for i in range(args.steps):
+            a = 0.004 * (i + 1)
+            ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+            cams.append((fs.cam_pos + np.float32(0.01 * (i + 1)) * np.array([1.0, 0.1, -0.5], np.float32), (fs.cam_mat @ ry).astype(np.float32)))
+        mv = {"rays": 0, "redone": 0}
+        timed_loop(min(args.steps, 2 * in_flight), False, cameras=cams)            # estimates adapt to a moving camera first
+        mv_elapsed = timed_loop(args.steps, False, cameras=cams, on_stats=lambda sk: mv.__setitem__("rays", mv["rays"] + sk.rays))
+        extra["moving_camera"] = {"ms_per_step": mv_elapsed / args.steps * 1e3, "value": mv["rays"] / mv_elapsed / 1e6, "unit": "Mrays/s",
+                                  "note": "the same loop with a new camera before every frame (hipexec_set_camera: 0.23 degrees of orbit and a "
+                                          "small dolly per frame); every frame is traced completely"}
+        for e in pipe.ex:
+            e.set_camera(fs.cam_pos, fs.cam_mat)
 
     t = torch.tensor([elapsed, float(agg["rays"]), 1.0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -420,10 +584,19 @@ def main(argv=None):
     if rank == 0:
         names = KNAMES[algo]
         tf = lambda f, ms: f / max(ms, 1e-9) / 1e9                       # FLOP, ms -> TFLOP/s
-        ach = tf(agg["exec_flop"], agg["ms"])
+        ach_overlapped = tf(agg["exec_flop"], agg["ms"])
+        ser = extra.get("serial")
+        if ser:      # launches that do not overlap: frames one at a time on one stream
+            ach = tf(ser["flop"][dom], ser["ms"][dom])
+            avg_launch_ms, launches_per_step = ser["ms"][dom] / max(1, ser["launches"][dom]), ser["launches"][dom] / ser["frames"]
+            basis = (f"{ser['frames']} frames rendered one at a time on one stream after the timed region (every launch timed with HIP events): "
+                     "launches that do not overlap")
+        else:        # no serial leg (N > 1, scan algorithms, --no-extra-legs): the timed region's own launches
+            ach, avg_launch_ms, launches_per_step = ach_overlapped, agg["ms"] / max(1, agg["launches"]), agg["launches"] / args.steps
+            basis = "launches of the timed region" + (" (frames in flight: they overlap)" if in_flight > 1 else "")
         q = pmc_quote(names[dom], args.workload, args.algo)
         roof = {"bound": "valu", "kernel": f"{names[dom]} ({KLABEL[dom]})", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS, "basis": basis,
                 "traffic": q.get("hbm_bytes_per_launch") if q else None,
                 "flop_model": (f"work the kernel executed, counted on the device: {F_NODE:.0f} FLOP per visited 4-wide node + 44 per exact "
                                "triangle test + 25 per sphere test") if algo == "bvh" else
@@ -432,14 +605,18 @@ def main(argv=None):
                 "flop_model_note": ("a fraction of the FLOP peak rewards instructions, not results: shortening the node step from 190 to 121 FLOP "
                                     "made the frame faster and this fraction smaller; the kernels are bound by their vector-instruction count "
                                     "(see pmc: rocprof VALUBusy)") if algo == "bvh" else None,
-                "avg_launch_ms": agg["ms"] / max(1, agg["launches"]), "launches_per_step": agg["launches"] / args.steps,
-                "kernel_ms_per_step": {f"{names[k]} ({KLABEL[k]})": probe_ms[k] for k in range(4)},
-                "kernel_ms_note": "all classes: one untimed frame with every launch timed; the timed steps time the dominant class only",
+                "avg_launch_ms": avg_launch_ms, "launches_per_step": launches_per_step,
+                "kernel_ms_per_step": ({f"{names[k]} ({KLABEL[k]})": ser["ms"][k] / ser["frames"] for k in range(4)} if ser else
+                                       {f"{names[k]} ({KLABEL[k]})": probe_ms[k] for k in range(4)}),
+                "kernel_ms_note": ("every class, launches that do not overlap (the serial frames); their sum is the device time of one frame alone on "
+                                   "one stream" if ser else "all classes: one untimed frame with every launch timed"),
+                "serial_frame_ms": ser["frame_ms"] / ser["frames"] if ser else None,
+                "class_frac": ({f"{names[k]} ({KLABEL[k]})": tf(ser["flop"][k], ser["ms"][k]) / PEAK_FP32_VALU_TFLOPS for k in range(3)} if ser else None),
                 "lanes": lanes, "frames_in_flight": in_flight,
-                "isolated": {"avg_launch_ms": probe_ms[dom] / max(1, probe_launches),
-                             "frac": probe_exec / max(probe_ms[dom], 1e-9) / 1e9 / PEAK_FP32_VALU_TFLOPS,
-                             "note": "the same launches in a frame that has the GPU to itself (the untimed probe frame); in the timed region "
-                                     "launches of the frames in flight overlap, so each takes longer while the frame rate is higher"},
+                "overlapped": {"avg_launch_ms": agg["ms"] / max(1, agg["launches"]), "launches_per_step": agg["launches"] / args.steps,
+                               "achieved": ach_overlapped, "frac": ach_overlapped / PEAK_FP32_VALU_TFLOPS,
+                               "note": "the same class's launches inside the timed region, where launches of the frames in flight share the chip: each "
+                                       "takes longer than alone and their durations sum to more than the wall time; not a serial quantity"},
                 "whole_frame": {"achieved": agg["exec_flop_all"] / max(elapsed, 1e-12) / 1e12, "frac": agg["exec_flop_all"] / max(elapsed, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                                 "note": "executed FLOP of all three ray classes of this rank / wall time of the timed region: what the chip "
                                         "delivered while launches of several frames shared it (the per-launch figure above divides by "
@@ -466,10 +643,20 @@ def main(argv=None):
             "config": {"workload": desc, "width": W, "height": H, "max_depth": depth, "triangles": fs.n_tri,
                        "spheres": fs.n_sph, "lamps": fs.n_lamp, "mode": "cpu-compat (ray_tracer.cpp semantics)",
                        "algorithm": args.algo, "frames_in_flight": in_flight,
+                       "what_a_step_is": (f"one complete frame; ms_per_step is the period of a loop that keeps {in_flight} frames in flight on "
+                                          f"{in_flight} executors of one device copy of the scene (the reference's timing loop, main.cpp:92-105, "
+                                          "also repeats one static frame); single_frame_ms is one frame at a time, first_frame_ms a frame with "
+                                          "no remembered launch sizes, moving_camera the loop with a new camera every frame"),
                        "partition": f"interleaved 8-row tiles over {world} GPU(s), gather to rank 0",
                        "rays_per_frame": rays_total / args.steps},
+            "frames_rendered": frames_rendered,
             "roofline": roof,
         }
+        for k in ("single_frame_ms", "first_frame_ms", "moving_camera"):
+            if k in extra:
+                res[k] = extra[k]
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         if world == 1 and algo == "bvh" and not args.no_brute:
             res["roofline_brute"] = brute_leg(fs, local_rank, step, st, args.workload)
         if world == 1 and not args.no_cpu_baseline:

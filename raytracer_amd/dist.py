@@ -36,15 +36,26 @@ def deinterleave(gathered: torch.Tensor, height: int) -> torch.Tensor:
     return x[:height].contiguous()
 
 
-def gather_frame(local: torch.Tensor, height: int, group=None, dst: int = 0):
+def gather_buffer(local: torch.Tensor, group=None, dst: int = 0):
+    """The [G][T_max*8][W][C] buffer rank `dst` receives the tile buffers in (None on the other ranks): allocated once
+    per output slot by a render loop and handed to every gather_frame of that slot."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 or dist.get_rank(group) != dst:
+        return None
+    return torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+
+
+def gather_frame(local: torch.Tensor, height: int, group=None, dst: int = 0, buf: torch.Tensor | None = None):
     """Gather every rank's compact tile buffer ([T_max*8][W][C], same shape on all ranks) to
-    rank `dst` and return the assembled frame there (None elsewhere)."""
+    rank `dst` and return the assembled frame there (None elsewhere).  `buf`: rank dst's receive buffer
+    (gather_buffer); without one a buffer is allocated for this call."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return deinterleave(local.unsqueeze(0), height)
     rank = dist.get_rank(group)
     if rank == dst:
-        buf = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        if buf is None:
+            buf = gather_buffer(local, group, dst)
         dist.gather(local, gather_list=[buf[i] for i in range(world)], dst=dst, group=group)
         return deinterleave(buf, height)
     dist.gather(local, gather_list=None, dst=dst, group=group)

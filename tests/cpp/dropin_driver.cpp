@@ -113,6 +113,13 @@ int main(int argc, char **argv)
         }
         wr(f, occ.data(), occ.size());
         for (size_t i = 0; i < rays.size(); i++) { float c[3] = {cols[i].x, cols[i].y, cols[i].z}; wr(f, c, 3); }
+        // the same executor handed a scene with another camera (ray_tracer_cl.cpp:80-92 makes the rays from the scene of the call)
+        Scene moved = scene;
+        moved.camPos = glm::vec3(scene.camPos.x + 0.75f, scene.camPos.y + 0.5f, scene.camPos.z - 1.25f);
+        image_bitmap blocks2(W, H);
+        for (int y = 0; y < H; y += SUB_BLOCK_HEIGHT) for (int x = 0; x < W; x += SUB_BLOCK_WIDTH)
+            renderSubBlockCl(blocks2, moved, ex, x, y, std::min(SUB_BLOCK_WIDTH, W - x), std::min(SUB_BLOCK_HEIGHT, H - y), W, H);
+        wr(f, static_cast<float *>(blocks2.getRawData()), (size_t)W * H * 3);
         fclose(f);
         return 0;
     }

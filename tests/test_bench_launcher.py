@@ -27,6 +27,12 @@ def test_gpus_2_starts_two_ranks_by_itself():
     assert len(lines) == 1                                   # rank 0 only
     r = lines[0]
     assert r["selftest"] and r["ok"] and r["n_gpus"] == 2 and r["ranks_seen"] == 2
+    # the per-rank diagnostics of an N > 1 line: one entry per rank, gathered to rank 0, every field a number
+    pr = r["per_rank"]
+    assert [e["rank"] for e in pr] == [0, 1]
+    for e in pr:
+        assert set(e) == {"rank", "frames", "frames_in_flight", "hw_queues", "compute_ms", "host_wait_ms", "gather_ms", "tiles"}
+        assert e["frames"] == 3 and e["tiles"] == 9 and e["gather_ms"] >= 0.0 and e["compute_ms"] >= 0.0      # tiny: 144 rows = 18 tiles
 
 
 def test_single_rank_runs_in_process():

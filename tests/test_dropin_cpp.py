@@ -1,8 +1,9 @@
 """The C++ drop-in (integration/ray_tracer_hip.cpp + scene_flatten.hpp), compiled against a
-test stand-in for the reference's types (tests/cpp/mock_reference.h; the reference's own
-headers need glm, which this image lacks).  CPU: it compiles and the Scene -> SoA flattening
-reproduces the arrays.  GPU: the five ray_tracer_cl.h functions give the CL-mode results of the
-oracle."""
+test stand-in for the reference's types (tests/cpp/mock_reference.h; the reference's scene.h
+needs glm, which this image lacks).  CPU: it compiles, also against the two headers of the
+reference that stand on their own (image_bitmap.h, config.h) where the reference tree exists,
+and the Scene -> SoA flattening reproduces the arrays.  GPU: the five ray_tracer_cl.h functions
+give the CL-mode results of the oracle."""
 import os
 import subprocess
 
@@ -14,16 +15,24 @@ from raytracer_amd import _abi, scenegen
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def driver(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("dropin") / "dropin_driver")
+REFERENCE = "/root/reference"
+
+
+def _build(out, extra=()):
     libdir = os.path.join(ROOT, "raytracer_amd", "lib")
     cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-ffp-contract=off",
-           '-DRT_HIP_REFERENCE_HEADER="mock_reference.h"',
+           '-DRT_HIP_REFERENCE_HEADER="mock_reference.h"', *extra,
            "-I", os.path.join(ROOT, "tests", "cpp"), "-I", os.path.join(ROOT, "integration"), "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "cpp", "dropin_driver.cpp"), os.path.join(ROOT, "integration", "ray_tracer_hip.cpp"),
            "-L", libdir, "-lhip_executor", f"-Wl,-rpath,{libdir}", "-o", out]
-    subprocess.run(cmd, check=True)
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dropin") / "dropin_driver")
+    r = _build(out)
+    assert r.returncode == 0, r.stderr
     return out
 
 
@@ -85,6 +94,35 @@ def test_flatten_reproduces_the_arrays(driver, tmp_path, name):
         assert (d["mat_kd"][extra] == 0).all() and (d["mat_color"][extra] == 0).all() and (d["mat_tex"][extra] == -1).all()
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "image_bitmap.h")), reason="the reference tree only exists in the build container")
+def test_dropin_compiles_against_the_references_standalone_headers(tmp_path):
+    """image_bitmap.h and config.h need nothing but the standard library, so here the drop-in and its driver are compiled
+    with the reference's OWN framebuffer class and block size in place of the stand-ins (-I/root/reference; nothing of
+    the reference travels: the GPU box keeps the stand-in build).  A drift between what ray_tracer_hip.cpp calls
+    (getWidth / getHeight / getRawData / setPixel) and what the reference's class offers fails this build."""
+    out = str(tmp_path / "dropin_driver_ref")
+    r = _build(out, ["-DRT_USE_REFERENCE_STANDALONE_HEADERS", "-I", REFERENCE])
+    assert r.returncode == 0, r.stderr
+    # ... and it is the reference's class that went in: the stand-in keeps its pixels in a std::vector named `d`,
+    # the reference's in `mData` (image_bitmap.h:13); config.h's guard macro is defined in that build only
+    probe = tmp_path / "probe.cpp"
+    probe.write_text('#define RT_USE_REFERENCE_STANDALONE_HEADERS\n#include "mock_reference.h"\n'
+                     "#ifndef RAY_TRACING_CONFIG_H\n#error config.h of the reference was not included\n#endif\n"
+                     "#ifndef RAY_TRACING_IMAGEBITMAP_H\n#error image_bitmap.h of the reference was not included\n#endif\n"
+                     "static_assert(SUB_BLOCK_WIDTH == 48 && SUB_BLOCK_HEIGHT == 48, \"block size\");\nint main() { image_bitmap b(3, 2); return b.getWidth() * 10 + b.getHeight() - 32; }\n")
+    exe = str(tmp_path / "probe")
+    subprocess.run(["g++", "-std=c++11", "-I", os.path.join(ROOT, "tests", "cpp"), "-I", REFERENCE, str(probe), "-o", exe], check=True)
+    assert subprocess.run([exe]).returncode == 0
+    # the flattening through that build gives the same arrays
+    fs = scenegen.small_variant("c2").to_flat()
+    src, dst = str(tmp_path / "scene.bin"), str(tmp_path / "flat.bin")
+    _dump(fs, src)
+    subprocess.run([out, "flatten", src, dst], check=True)
+    d = _load(dst)
+    assert np.array_equal(d["tri_p"].view(np.int32), fs.tri_p.reshape(-1).view(np.int32))
+    assert np.array_equal(d["cam_mat"].view(np.int32), fs.cam_mat.reshape(-1).view(np.int32))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ties", "c2"])
 def test_dropin_functions_match_the_cl_mode_oracle(driver, tmp_path, name):
@@ -107,7 +145,8 @@ def test_dropin_functions_match_the_cl_mode_oracle(driver, tmp_path, name):
     blocks = raw[off:off + W * H * 12].view(np.float32).reshape(H, W, 3); off += W * H * 12
     hits = raw[off:off + n * 48].view(np.float32).reshape(n, 12); off += n * 48
     occ = raw[off:off + n].view(np.int8); off += n
-    cols = raw[off:off + n * 12].view(np.float32).reshape(n, 3)
+    cols = raw[off:off + n * 12].view(np.float32).reshape(n, 3); off += n * 12
+    moved = raw[off:off + W * H * 12].view(np.float32).reshape(H, W, 3)
     orc = Oracle(fs)
     ref = orc.render(W, H, mode=_abi.HIPEXEC_MODE_CL, tone=1)
     assert_image_parity(full, ref["rgb"], min_frac=1.0)
@@ -127,3 +166,10 @@ def test_dropin_functions_match_the_cl_mode_oracle(driver, tmp_path, name):
     assert np.array_equal(occ != 0, orc.any_hits(rays, _abi.HIPEXEC_MODE_CL, hits=pre) != 0)
     base = np.tile(np.array([0.5, 0.25, 0.125], np.float32), (n, 1))
     assert ulp_diff(cols, orc.trace_rays(rays, _abi.HIPEXEC_MODE_CL, colours=base)).max() <= 4
+    # renderSubBlockCl with a scene whose camera differs from the executor's: the frame of THAT camera
+    import copy
+    fs2 = copy.copy(fs)
+    fs2.cam_pos = (fs.cam_pos + np.array([0.75, 0.5, -1.25], np.float32)).astype(np.float32)
+    ref2 = Oracle(fs2).render(W, H, mode=_abi.HIPEXEC_MODE_CL, tone=1)
+    assert_image_parity(moved, ref2["rgb"], min_frac=1.0)
+    assert not np.array_equal(moved, full)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarises gpurun_out/prof_<tag> (written by tools/profile_round.sh) into profiles/<tag>_*:
-kernel stats CSV, per-kernel PMC totals and derived metrics (VALU utilisation, HBM traffic with
-the gfx950 FETCH_SIZE correction, L2 hit rate)."""
+kernel stats CSVs (frames in flight; frames one at a time; the default command), every pass's bench line, and per-kernel
+PMC totals with derived metrics (VALU issue fraction, live lanes, HBM traffic with the gfx950 FETCH_SIZE correction, L2
+hit rate).  Per-frame figures divide by the number of frames the pass itself reports (`frames_rendered` of its bench
+line), never by a constant; the clock the counters imply (GRBM_GUI_ACTIVE over the serial trace's kernel time) must
+come out at or below the part's 2.4 GHz, or the normalisation is wrong and the script fails."""
 import collections
 import csv
 import glob
@@ -9,6 +12,9 @@ import json
 import os
 import shutil
 import sys
+
+MAX_CLOCK_GHZ = 2.5
+
 
 def newest(pattern):
     """One file per pass directory: gpurun merges each run's files into the local copy, so earlier runs' files stay."""
@@ -20,74 +26,119 @@ def newest(pattern):
     return list(by_dir.values())
 
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = f"gpurun_out/prof_{tag}"
-os.makedirs("profiles", exist_ok=True)
-for f in newest(f"{src}/trace/*/*kernel_stats.csv"):
-    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
-# the default command (python bench.py, as the driver runs it): its kernel stats and its JSON line
-for f in newest(f"{src}/trace_default/*/*kernel_stats.csv"):
-    shutil.copy(f, f"profiles/{tag}_default_cmd_kernel_stats.csv")
-for log, name in ((f"{src}/trace_default.log", f"profiles/{tag}_default_cmd_bench.json"), (f"{src}/trace.log", f"profiles/{tag}_trace_cmd_bench.json")):
-    if os.path.exists(log):
-        lines = [l for l in open(log, errors="replace") if l.startswith('{"metric"')]
-        if lines:
-            open(name, "w").write(lines[-1])
-tot = collections.defaultdict(lambda: collections.defaultdict(float))
-disp = collections.defaultdict(int)
-for f in newest(f"{src}/pmc_*/*/*counter_collection.csv"):
-    seen = set()
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "rt::k_" not in k:
-            continue
-        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if "pmc_sq/" in f.replace("\\", "/") and r["Counter_Name"] == "SQ_WAVES":
-            disp[k] += 1
-# kernel durations from the trace (same command line: 1 warm-up + 1 probe + 2 timed frames)
-dur = collections.defaultdict(float); calls = collections.defaultdict(int)
-for f in newest(f"{src}/trace/*/*kernel_trace.csv"):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "rt::k_" in k:
-            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; calls[k] += 1
-out = {}
-N_SIMD = 1024
-# bench.py renders warm-up frames, one probe frame (every class timed) and the timed steps with the chosen algorithm:
-# --steps 2 --warmup 1 in the trace run, --steps 1 --warmup 0 in the PMC runs
-TRACE_FRAMES, PMC_FRAMES = 4.0, 2.0
-for k, c in tot.items():
-    d = dict(c)
-    ms_frame = dur[k] / TRACE_FRAMES if k in dur else None
-    gui = d.get("GRBM_GUI_ACTIVE", 0) / 8.0                 # summed over the 8 XCDs
-    m = {"counters": d, "counters_cover_frames": PMC_FRAMES, "ms_per_frame_from_trace": ms_frame,
-         "launches_per_frame": calls[k] / TRACE_FRAMES if k in calls else None}
-    if gui:
-        m["clock_ghz"] = gui / (ms_frame * PMC_FRAMES * 1e6) if ms_frame else None
-        # the SIMDs are 32 lanes wide: with two or more waves resident a SIMD issues one wave64 VALU instruction per
-        # 2 cycles (the 157.3 TFLOP/s FP32 peak is that rate), so the fraction of the issue peak is instructions x 2 /
-        # SIMD-cycles.  SQ_ACTIVE_INST_VALU (quad-cycles a wave spends in VALU instructions, 4 cycles each for a wave
-        # alone) over the same cycles can exceed 1 when waves overlap and is kept under its own name.
-        m["valu_issue_fraction"] = d.get("SQ_INSTS_VALU", 0) * 2.0 / (gui * N_SIMD)
-        m["valu_wave_busy"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
-        # rocprofiler-sdk's own derived metrics for gfx950 (share/rocprofiler-sdk/counter_defs.yaml):
-        #   VALUBusy = 100 * sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE)   (= valu_wave_busy in percent; it can
-        #   exceed 100 because two waves of a SIMD overlap their VALU instructions)
-        #   VALUUtilization = 100 * sum(SQ_THREAD_CYCLES_VALU) / (sum(SQ_ACTIVE_INST_VALU) * 64)   (live lanes)
-        m["rocprof_VALUBusy_pct"] = 100.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / 256.0 / gui
-        if d.get("SQ_ACTIVE_INST_VALU"):
-            m["rocprof_VALUUtilization_pct"] = 100.0 * d.get("SQ_THREAD_CYCLES_VALU", 0) / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
-        m["occupancy_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0) * 4.0 / (gui * N_SIMD)
-    if "FETCH_SIZE" in d:
-        # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reads half of a wide coalesced stream on gfx950 (x2 upper bound)
-        # (bytes per frame)
-        m["hbm_read_bytes_low"] = d["FETCH_SIZE"] * 1024.0 / PMC_FRAMES
-        m["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 2048.0 / PMC_FRAMES
-    if "WRITE_SIZE" in d:
-        m["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024.0 / PMC_FRAMES
-    if d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0) > 0:
-        m["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
-    out[k] = m
-json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
-for k, m in sorted(out.items()):
-    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in m.items() if a != "counters"})
+def bench_line(log):
+    """The JSON line bench.py printed in a pass, or None."""
+    if not os.path.exists(log):
+        return None
+    lines = [l for l in open(log, errors="replace") if l.startswith('{"metric"')]
+    return json.loads(lines[-1]) if lines else None
+
+
+def kname(row):
+    return row["Kernel_Name"].split("(")[0].replace("void ", "")
+
+
+def trace_of(src, which):
+    """-> (total ms, calls) per kernel of a kernel-trace pass"""
+    dur = collections.defaultdict(float); calls = collections.defaultdict(int)
+    for f in newest(f"{src}/{which}/*/*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            k = kname(r)
+            if "rt::k_" in k:
+                dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; calls[k] += 1
+    return dur, calls
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03_bvh"
+    src = f"gpurun_out/prof_{tag}"
+    algo_key = "scan" if ("brute" in tag or "scan" in tag) else "bvh"
+    os.makedirs("profiles", exist_ok=True)
+    for which, name in (("trace", "kernel_stats"), ("trace_serial", "serial_kernel_stats"), ("trace_default", "default_cmd_kernel_stats")):
+        for f in newest(f"{src}/{which}/*/*kernel_stats.csv"):
+            shutil.copy(f, f"profiles/{tag}_{name}.csv")
+    lines = {}
+    for which, name in (("trace", "trace_cmd_bench"), ("trace_serial", "serial_cmd_bench"), ("trace_default", "default_cmd_bench")):
+        lines[which] = bench_line(f"{src}/{which}.log")
+        if lines[which]:
+            json.dump(lines[which], open(f"profiles/{tag}_{name}.json", "w"))
+
+    def frames_of(which):
+        b = bench_line(f"{src}/{which}.log")
+        if not b or "frames_rendered" not in b:
+            raise SystemExit(f"{src}/{which}.log holds no bench line with frames_rendered: cannot normalise per frame")
+        return float(b["frames_rendered"][algo_key])
+
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    pass_frames = {}
+    waves = collections.defaultdict(float)
+    for f in newest(f"{src}/pmc_*/*/*counter_collection.csv"):
+        which = f.split("/")[2]
+        pass_frames[which] = frames_of(which)
+        for r in csv.DictReader(open(f)):
+            k = kname(r)
+            if "rt::k_" not in k:
+                continue
+            # per frame of the pass that collected the counter
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"]) / pass_frames[which]
+            if r["Counter_Name"] == "SQ_WAVES":
+                waves[k] += float(r["Counter_Value"])
+    # kernel durations: frames one at a time (what a launch takes alone) and frames in flight
+    ser_frames, ovl_frames = frames_of("trace_serial"), frames_of("trace")
+    ser_dur, ser_calls = trace_of(src, "trace_serial")
+    ovl_dur, ovl_calls = trace_of(src, "trace")
+    out = {}
+    N_SIMD = 1024
+    for k, c in tot.items():
+        d = dict(c)                                          # every counter: per frame
+        ms_frame = ser_dur[k] / ser_frames if k in ser_dur else None
+        gui = d.get("GRBM_GUI_ACTIVE", 0) / 8.0              # summed over the 8 XCDs
+        m = {"counters_per_frame": d, "frames_in_pass": pass_frames,
+             "ms_per_frame_serial": ms_frame, "launches_per_frame": ser_calls[k] / ser_frames if k in ser_calls else None,
+             "avg_launch_ms_serial": ser_dur[k] / ser_calls[k] if ser_calls.get(k) else None,
+             "ms_per_frame_in_flight": ovl_dur[k] / ovl_frames if k in ovl_dur else None,
+             "avg_launch_ms_in_flight": ovl_dur[k] / ovl_calls[k] if ovl_calls.get(k) else None}
+        if gui:
+            if ms_frame:
+                m["clock_ghz"] = gui / (ms_frame * 1e6)
+                if m["clock_ghz"] > MAX_CLOCK_GHZ and ms_frame > 0.02:
+                    raise SystemExit(f"{k}: the counters imply a clock of {m['clock_ghz']:.2f} GHz: frames are miscounted")
+            # the SIMDs are 32 lanes wide: with two or more waves resident a SIMD issues one wave64 VALU instruction per
+            # 2 cycles (the 157.3 TFLOP/s FP32 peak is that rate), so the fraction of the issue peak is instructions x 2 /
+            # SIMD-cycles.  SQ_ACTIVE_INST_VALU (quad-cycles a wave spends in VALU instructions, 4 cycles each for a wave
+            # alone) over the same cycles can exceed 1 when waves overlap and is kept under its own name.
+            m["valu_issue_fraction"] = d.get("SQ_INSTS_VALU", 0) * 2.0 / (gui * N_SIMD)
+            m["valu_wave_busy"] = d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (gui * N_SIMD)
+            # rocprofiler-sdk's own derived metrics for gfx950 (share/rocprofiler-sdk/counter_defs.yaml):
+            #   VALUBusy = 100 * sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE)   (= valu_wave_busy in percent; it can
+            #   exceed 100 because two waves of a SIMD overlap their VALU instructions)
+            #   VALUUtilization = 100 * sum(SQ_THREAD_CYCLES_VALU) / (sum(SQ_ACTIVE_INST_VALU) * 64)   (live lanes)
+            m["rocprof_VALUBusy_pct"] = 100.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / 256.0 / gui
+            if d.get("SQ_ACTIVE_INST_VALU"):
+                m["rocprof_VALUUtilization_pct"] = 100.0 * d.get("SQ_THREAD_CYCLES_VALU", 0) / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
+                m["live_lane_fraction"] = d.get("SQ_THREAD_CYCLES_VALU", 0) / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
+            m["occupancy_waves_per_simd"] = d.get("SQ_WAVE_CYCLES", 0) * 4.0 / (gui * N_SIMD)
+        if d.get("SQ_WAVE_CYCLES"):
+            m["wait_fraction_of_wave_cycles"] = d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+        if d.get("SQ_WAVES"):
+            m["valu_insts_per_wave"] = d.get("SQ_INSTS_VALU", 0) / d["SQ_WAVES"]
+        if "FETCH_SIZE" in d:
+            # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reads half of a wide coalesced stream on gfx950 (x2 upper bound)
+            m["hbm_read_bytes_low"] = d["FETCH_SIZE"] * 1024.0
+            m["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 2048.0
+        if "WRITE_SIZE" in d:
+            m["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024.0
+        if "hbm_read_bytes_corrected" in m and "hbm_write_bytes" in m and m["launches_per_frame"]:
+            m["hbm_bytes_per_launch"] = (m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]) / m["launches_per_frame"]
+        if d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0) > 0:
+            m["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+            if m["launches_per_frame"]:
+                m["l2_miss_bytes_per_launch"] = d["TCC_MISS_sum"] * 128.0 / m["launches_per_frame"]      # 128-byte lines: cross-check of hbm_bytes_per_launch
+        out[k] = m
+    json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    for k, m in sorted(out.items()):
+        print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in m.items() if a not in ("counters_per_frame", "frames_in_pass")})
+
+
+if __name__ == "__main__":
+    main()
