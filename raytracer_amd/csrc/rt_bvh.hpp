@@ -45,6 +45,10 @@ constexpr int BVH_LEAF_MAX = 2;
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 5
 #endif
+#ifndef RT_BVH_SPLIT_LEAVES
+#define RT_BVH_SPLIT_LEAVES 1                   // free slots of a node are filled by opening its two-triangle leaves, see k_bvh_emit
+#endif
+constexpr bool BVH_SPLIT_LEAVES = RT_BVH_SPLIT_LEAVES != 0;
 constexpr int BVH_STACK = RT_BVH_STACK;         // LDS stack entries per lane (a node pushes up to three)
 constexpr uint32_t BVH_MAX_TRIS = 1u << 28;
 constexpr float BVH_LOOSE = 3.0e-2f;            // see TRay
@@ -296,6 +300,25 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
         uint32_t c = slot[pick];
         slot[pick] = child[2 * c];
         slot[ns++] = child[2 * c + 1];
+    }
+    // Slots still free (the node's subtree has only leaves left): a walk tests all four slots of a record anyway, so a
+    // free slot costs what a used one does.  Two-triangle leaves are therefore opened into their two triangles, largest
+    // box first, while slots are free: each triangle then has a box of its own and fewer exact tests are reached.
+    if (BVH_SPLIT_LEAVES) {
+        while (ns < 4) {
+            int pick = -1; float best_area = -1.0f;
+            for (int k = 0; k < ns; k++) {
+                if (slot[k] >= n - 1) continue;                           // a single triangle already
+                float4 lo = box_lo[slot[k]], hi = box_hi[slot[k]];
+                float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+                float area = dx * dy + dy * dz + dz * dx;
+                if (area > best_area) { best_area = area; pick = k; }
+            }
+            if (pick < 0) break;
+            uint32_t c = slot[pick];
+            slot[pick] = child[2 * c];
+            slot[ns++] = child[2 * c + 1];
+        }
     }
     // what belongs to the node as a whole travels in the w words of the four lo entries, so that the record is one
     // 128-byte cache line: A of all the node's triangles (the largest of its slots' values) and the cone

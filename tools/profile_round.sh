@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 COMMON="--no-cpu-baseline --no-brute --no-extra-legs --algo $ALGO"
 SERIAL="--frames-in-flight 1 --lanes-per-frame 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py --steps 4 --warmup 1 $COMMON > "$OUT/trace.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -- python bench.py --steps 4 --warmup 1 $SERIAL $COMMON > "$OUT/trace_serial.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -- python bench.py --steps 12 --warmup 1 $SERIAL $COMMON > "$OUT/trace_serial.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM --output-format csv -d "$OUT/pmc_sq" -- python bench.py --steps 1 --warmup 0 $SERIAL $COMMON > "$OUT/pmc_sq.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_sq2" -- python bench.py --steps 1 --warmup 0 $SERIAL $COMMON > "$OUT/pmc_sq2.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 1 --warmup 0 $SERIAL $COMMON > "$OUT/pmc_fetch.log" 2>&1
