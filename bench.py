@@ -179,8 +179,7 @@ def executed_flops_bvh(st, k, n_sph):
     """FLOP the hierarchy kernels evaluated for a ray class (node visits + exact tests + sphere tests, counted on the device)."""
     if k >= 3:
         return 0.0
-    rays = [st.rays_primary, st.rays_bounce, st.rays_shadow][k]
-    return st.bvh_nodes[k] * F_NODE + st.bvh_tests[k] * F_TRI + rays * n_sph * F_SPH
+    return st.bvh_nodes[k] * F_NODE + st.bvh_tests[k] * F_TRI + st.bvh_sph_tests[k] * F_SPH
 
 
 def executed_flops_scan(st, k):
@@ -467,6 +466,7 @@ def main(argv=None):
     probe_ms = [float(st.kernel_ms[k]) for k in range(4)]
     dom = max(range(3), key=lambda k: probe_ms[k])
     agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop", "exec_flop_all")}
+    walk = {"rays": [0, 0, 0], "nodes": [0, 0, 0], "tests": [0, 0, 0], "overflows": 0}      # per ray class: camera, bounce, shadow
 
     def account(s):
         agg["rays"] += s.rays
@@ -474,6 +474,9 @@ def main(argv=None):
         agg["exec_flop"] += executed_flops_bvh(s, dom, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, dom)
         agg["exec_flop_all"] += sum((executed_flops_bvh(s, k, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, k)) for k in range(3))
         agg["equiv_flop"] += ref_flops[dom] if ref_flops is not None else scan_equiv_flops(s, dom, fs.n_sph)
+        for k, r in enumerate((s.rays_primary, s.rays_bounce, s.rays_shadow)):
+            walk["rays"][k] += int(r); walk["nodes"][k] += int(s.bvh_nodes[k]); walk["tests"][k] += int(s.bvh_tests[k])
+        walk["overflows"] += int(s.bvh_stack_overflows)
 
 
     def timed_loop(n_steps, time_classes, cameras=None, on_stats=None):
@@ -627,6 +630,9 @@ def main(argv=None):
                                             "(-ffp-contract=off), 1 FLOP per lane and slot, so half the peak is the most this code could reach "
                                             "with every lane live and every slot carrying a FLOP; compares, min/max and selects (about 40 % of "
                                             "a node step) carry none"},
+                "walk_per_ray": ({KLABEL[k]: {"nodes": walk["nodes"][k] / max(1, walk["rays"][k]), "exact_tests": walk["tests"][k] / max(1, walk["rays"][k])}
+                                  for k in range(3)} if algo == "bvh" else None),
+                "stack_overflows_per_step": walk["overflows"] / args.steps,
                 "limiter": limiter_of(q, ach / PEAK_FP32_VALU_TFLOPS if algo != "bvh" else 0.0), "pmc": q,
                 "scan_equivalent": {"tflops": tf(agg["equiv_flop"], agg["ms"]),
                                     "note": "FLOP the reference's linear scans would have spent on the same rays (44 per ray-triangle test, every "
