@@ -196,10 +196,6 @@ typedef struct hipexec_stats {
                                      nodes visited, summed over rays (HIPEXEC_ALGO_BVH)            */
     uint64_t bvh_tests[3];        /* per ray class: exact ray-triangle tests evaluated, summed over
                                      rays (HIPEXEC_ALGO_BVH)                                       */
-    uint64_t bvh_sph_tests[3];    /* per ray class: exact ray-sphere tests evaluated (HIPEXEC_ALGO_BVH): spheres are
-                                     primitives of the hierarchy, so a ray tests the few its walk leads to, or all
-                                     of them where the sphere boxes do not cover the ray (far origins, directions
-                                     shorter than 1)                                               */
     uint64_t bvh_stack_overflows; /* rays whose traversal stack overflowed and that were finished by a
                                      linear scan instead (same result, slow); expected 0          */
     uint32_t algorithm;           /* HIPEXEC_ALGO_* the call ran with                             */

@@ -55,7 +55,7 @@ class Stats(C.Structure):
         ("tests_tri_closest", C.c_uint64), ("tests_sph_closest", C.c_uint64),
         ("tests_tri_any", C.c_uint64), ("tests_sph_any", C.c_uint64),
         ("tests_tri_primary", C.c_uint64), ("exact_groups", C.c_uint64 * 3), ("scanned_chunks", C.c_uint64 * 3),
-        ("bvh_nodes", C.c_uint64 * 3), ("bvh_tests", C.c_uint64 * 3), ("bvh_sph_tests", C.c_uint64 * 3), ("bvh_stack_overflows", C.c_uint64), ("algorithm", C.c_uint32), ("lanes", C.c_uint32),
+        ("bvh_nodes", C.c_uint64 * 3), ("bvh_tests", C.c_uint64 * 3), ("bvh_stack_overflows", C.c_uint64), ("algorithm", C.c_uint32), ("lanes", C.c_uint32),
         ("launches", C.c_uint32 * K_COUNT), ("kernel_ms", C.c_float * K_COUNT), ("total_ms", C.c_float),
     ]
 
@@ -67,7 +67,6 @@ class Stats(C.Structure):
         d["scanned_chunks"] = [int(x) for x in self.scanned_chunks]
         d["bvh_nodes"] = [int(x) for x in self.bvh_nodes]
         d["bvh_tests"] = [int(x) for x in self.bvh_tests]
-        d["bvh_sph_tests"] = [int(x) for x in self.bvh_sph_tests]
         d["bvh_stack_overflows"] = int(self.bvh_stack_overflows)
         d["launches"] = list(self.launches)
         d["kernel_ms"] = [float(x) for x in self.kernel_ms]

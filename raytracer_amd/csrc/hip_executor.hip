@@ -267,7 +267,7 @@ constexpr uint64_t SHADOW_QUEUE_MAX_ENTRIES = 96ull << 20;   // 3 GiB of 32-byte
 constexpr uint32_t BATCH_API_CHUNK = 4u << 20;               // rays per chunk of the batch entry points
 constexpr uint64_t BATCH_MAX_SAMPLES = 64ull << 20;          // samples per batch of a frame without a shadow queue
 constexpr uint32_t TAIL_MAX_RAYS = 300000u;                    // see use_tail
-constexpr int N_CNT64 = 20;                                  // device counters in use per stripe, see call_end
+constexpr int N_CNT64 = 17;                                  // device counters in use per stripe, see call_end
 constexpr size_t CNT64_WORDS = (size_t)CNT_STRIPES * CNT_STRIDE;   // all stripes
 static_assert(N_CNT64 <= (int)CNT_STRIDE, "counters fit a stripe");
 constexpr int LV_SLOTS = 8;                                  // batches of one call (per lane) whose level counts are kept apart
@@ -497,20 +497,14 @@ int validate_scene(const hipexec_scene_desc *s)
     return HIPEXEC_OK;
 }
 
-// Hierarchy over the triangles and spheres (rt_bvh.hpp).  Scenes with non-finite or astronomically large
-// coordinates, or too many primitives for the leaf encoding, get none and are always scanned; spheres whose radii are
-// not finite stay out of it (every ray then tests the spheres in index order, as the scans do).
-int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const double *hi, bool all_finite, bool sph_finite)
+// Hierarchy over the triangles (rt_bvh.hpp).  Scenes with non-finite or astronomically large
+// coordinates, or too many triangles for the leaf encoding, get none and are always scanned.
+int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const double *hi, bool all_finite)
 {
     const DScene &S = h->S;
     DBvh &B = h->B;
-    B.sph_in = (sph_finite && all_finite) ? 1u : 0u;
-    if (const char *e = knob("HIPEXEC_SPH_IN_BVH")) { if (atoi(e) == 0) B.sph_in = 0u; }     // A/B and test aid: every ray tests every sphere
-    const uint32_t n = S.n_tri + (B.sph_in ? S.n_sph : 0u);
-    B.n = n; B.n_tri = S.n_tri; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
-    for (int k = 0; k < 3; k++) B.sph_center[k] = S.center[k];
-    B.sph_rmax2 = S.rmax * S.rmax;
-    if (!(B.sph_rmax2 < 3.0e38f)) B.sph_in = 0u;
+    const uint32_t n = S.n_tri;
+    B.n = n; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
     B.stack_limit = BVH_STACK;
     if (const char *e = knob("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
     B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
@@ -520,17 +514,14 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         const double want = std::max(1.0e30, 1.0e12 * (double)B.scene_mag * (double)B.scene_mag);
         B.inv_clamp = want < 3.0e38 ? (float)want : std::numeric_limits<float>::infinity();
     }
-    h->bvh_ok = all_finite && (uint64_t)S.n_tri + S.n_sph <= BVH_MAX_TRIS;
+    h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
     CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 3));      // + one record: a one-triangle leaf is fetched as two
     CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
     CHK(upload<float4>(h, nullptr, 0, &nodes, BVH_NODE_F4 * (size_t)n + 1));
     B.tris = tris; B.ids = ids; B.nodes = nodes;
     if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
-    // a scene of one primitive, or of two triangles, is a leaf; everything else has inner node 0 as its root
-    if (n == 1) B.root = BVH_LEAF | ((S.n_tri == 1 ? 1u : BVH_LEAF_SPHERE) << 28);
-    else if (n == 2 && S.n_tri == 2) B.root = BVH_LEAF | (2u << 28);
-    else B.root = 0u;
+    B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
 
     // temporaries: one block, carved up, released at the end
     unsigned long long *keys_a = nullptr, *keys_b = nullptr;
@@ -561,11 +552,10 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         float emax = std::max(ext[0], std::max(ext[1], ext[2]));
         inv.x = inv.y = inv.z = emax > 0.f ? 1.0f / emax : 0.f;
         const dim3 blk(256), grid((n + 255) / 256);
-        hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, S.n_tri, tri_exact, S.sph, flo, inv, keys_a);
+        hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
-        hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, S.n_tri, keys_b, tri_exact, S.sph, SPH_GROW_V * 2.0f * S.rmax + 1.0e-30f,
-                           tris, ids, box_lo, box_hi, nrm_lo, nrm_hi);
+        hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi, nrm_lo, nrm_hi);
         HIPCHK(hipGetLastError());
         if (n >= 2) {
             hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range, top_list, top_count);
@@ -574,7 +564,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
                                box_lo, box_hi, nrm_lo, nrm_hi);
             hipLaunchKernelGGL(k_bvh_refit_top, dim3(1), dim3(1024), 0, h->stream, n, child, range, top_list, top_count, arrived, box_lo, box_hi, nrm_lo, nrm_hi);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, S.n_tri, ids, child, range, box_lo, box_hi, nrm_lo, nrm_hi, nodes);
+            hipLaunchKernelGGL(k_bvh_emit, grid, blk, 0, h->stream, n, child, range, box_lo, box_hi, nrm_lo, nrm_hi, nodes);
             HIPCHK(hipGetLastError());
         }
         return HIPEXEC_OK;
@@ -693,19 +683,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
     }
     STAGE("triangle upload + exact");
-    // spheres: primitives of the hierarchy as well
-    std::vector<float4> sph(std::max(1u, s->n_sph));
-    std::vector<int> smat(std::max(1u, s->n_sph), (int)s->n_mat);
-    bool sph_finite = true;
-    for (uint32_t i = 0; i < s->n_sph; i++) {
-        sph[i] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
-        smat[i] = (s->sph_mat && s->sph_mat[i] >= 0) ? s->sph_mat[i] : (int)s->n_mat;
-        sph_finite = sph_finite && std::fabs(s->sph_radius[i]) < 1e18f;          // false for NaN and infinities too
-    }
-    float4 *d_sph = nullptr; int *d_smat = nullptr;
-    CHK(upload(h, sph.data(), sph.size(), &d_sph)); CHK(upload(h, smat.data(), smat.size(), &d_smat));
-    S.sph = d_sph; S.sph_mat = d_smat;
-    CHK(build_bvh(h, ex, lo, hi, all_finite, sph_finite));
+    CHK(build_bvh(h, ex, lo, hi, all_finite));
     STAGE("hierarchy build");
     // what the build does not read goes up on the side stream while the build's kernels run
     h->upload_stream = h->side;
@@ -717,6 +695,17 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
     for (uint32_t i = 0; i < s->n_tri; i++) tmat[i] = (s->tri_mat && s->tri_mat[i] >= 0) ? s->tri_mat[i] : (int)s->n_mat;
     CHK(upload(h, tmat.data(), tmat.size(), &d_tmat));
     S.tri_norm = d_norm; S.tri_uv = d_uv; S.tri_mat = d_tmat;
+
+    // spheres
+    std::vector<float4> sph(std::max(1u, s->n_sph));
+    std::vector<int> smat(std::max(1u, s->n_sph), (int)s->n_mat);
+    for (uint32_t i = 0; i < s->n_sph; i++) {
+        sph[i] = make_float4(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2], s->sph_radius[i]);
+        smat[i] = (s->sph_mat && s->sph_mat[i] >= 0) ? s->sph_mat[i] : (int)s->n_mat;
+    }
+    float4 *d_sph = nullptr; int *d_smat = nullptr;
+    CHK(upload(h, sph.data(), sph.size(), &d_sph)); CHK(upload(h, smat.data(), smat.size(), &d_smat));
+    S.sph = d_sph; S.sph_mat = d_smat;
 
     // materials; entry n_mat is the default Material() of scene.h:32-44
     std::vector<float4> ma(s->n_mat + 1), mb(s->n_mat + 1);
@@ -899,7 +888,7 @@ void add_stats(hipexec_stats &d, const hipexec_stats &a)
     d.bvh_stack_overflows += a.bvh_stack_overflows;
     for (int k = 0; k < 3; k++) {
         d.exact_groups[k] += a.exact_groups[k]; d.scanned_chunks[k] += a.scanned_chunks[k];
-        d.bvh_nodes[k] += a.bvh_nodes[k]; d.bvh_tests[k] += a.bvh_tests[k]; d.bvh_sph_tests[k] += a.bvh_sph_tests[k];
+        d.bvh_nodes[k] += a.bvh_nodes[k]; d.bvh_tests[k] += a.bvh_tests[k];
     }
     for (int k = 0; k < HIPEXEC_K_COUNT; k++) { d.launches[k] += a.launches[k]; d.kernel_ms[k] += a.kernel_ms[k]; }
 }
@@ -917,7 +906,6 @@ int call_end(hipexec *h, hipexec_stats *stats)
     for (int k = 0; k < 3; k++) {
         h->acc.exact_groups[k] = h->h_cnt64[2 + k]; h->acc.scanned_chunks[k] = h->h_cnt64[5 + k];
         h->acc.bvh_nodes[k] = h->h_cnt64[8 + k]; h->acc.bvh_tests[k] = h->h_cnt64[11 + k];
-        h->acc.bvh_sph_tests[k] = h->h_cnt64[17 + k];
     }
     h->acc.rays_shadow += h->h_cnt64[14];
     h->acc.bvh_stack_overflows = h->h_cnt64[15];
