@@ -61,6 +61,8 @@ WORKLOADS = {
     "c1": ("scene_c1", {}, 640, 480, 0, "C1: ~1k tris + 8 spheres, 1 lamp, 640x480, 4 spp, depth 0"),
     "c4": ("scene_c4", {}, 1920, 1080, 0, "C4: 10k tris, 8 x 2048^2 textures, 1920x1080, depth 0"),
     "c5": ("scene_c5", {}, 3840, 2160, 0, "C5: 20k tris + 16 spheres, 16 lamps, 3840x2160, depth 0"),
+    "soup": ("scene_soup", {"seed": 105, "n_tri": 40000, "extent": 50.0}, 640, 480, 3,
+             "soup: 40000 random triangles up to scene size (a few rays per frame outgrow the traversal stack), 640x480, depth 3"),
     "tiny": ("scene_c2", {"cells": 24, "tex_size": 64}, 256, 144, 3, "tiny: 1152-tri C2 variant at 256x144 (functional check only)"),
 }
 
@@ -179,7 +181,8 @@ def executed_flops_bvh(st, k, n_sph):
     """FLOP the hierarchy kernels evaluated for a ray class (node visits + exact tests + sphere tests, counted on the device)."""
     if k >= 3:
         return 0.0
-    return st.bvh_nodes[k] * F_NODE + st.bvh_tests[k] * F_TRI + st.bvh_sph_tests[k] * F_SPH
+    rays = [st.rays_primary, st.rays_bounce, st.rays_shadow][k]
+    return st.bvh_nodes[k] * F_NODE + st.bvh_tests[k] * F_TRI + rays * n_sph * F_SPH
 
 
 def executed_flops_scan(st, k):
