@@ -112,6 +112,40 @@ def test_c3_4k_depth5_shards_of_eight():
         assert_image_parity(a["rgb"][y:y + 8, x:x + 8], ref["rgb"], min_frac=1.0)
 
 
+def test_c3_4k_depth5_refraction():
+    """Benchmark config 3 names "reflect/refract"; the reference has no refraction (only the two unused Material fields,
+    scene.h:28-29), so this is the opt-in mode at the configuration's size: the C2 scene with its four spheres made of
+    glass, 3840x2160, depth 5, whole frame in one call.  Blocks that look at the spheres and a regular grid against the
+    mode's definition in the oracle; the ray counts differ from the mirror frame's."""
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = scenegen.scene_c2().to_flat()
+    nm = int(fs.mat_kd.shape[0])
+    kt, ior = np.zeros(nm, np.float32), np.zeros(nm, np.float32)
+    for mi in np.unique(fs.sph_mat):
+        kt[mi], ior[mi] = 0.7, 1.45
+    fs.mat_kt, fs.mat_ior = kt, ior
+    W, H, depth = 3840, 2160, 5
+    with HipExecutor(fs, device=0) as ex:
+        a = ex.render(W, H, max_depth=depth, refract=True)
+        b = ex.render(W, H, max_depth=depth, refract=True, want_ids=False)
+        m = ex.render(W, H, max_depth=depth, want_ids=False)
+    assert np.array_equal(a["rgb"].view(np.int32), b["rgb"].view(np.int32)), "render is not deterministic"
+    assert a["stats"].rays_bounce != m["stats"].rays_bounce and not np.array_equal(a["rgb"], m["rgb"])
+    assert a["stats"].bvh_stack_overflows == 0
+    # 8x8 blocks whose first sample hits a sphere, spread over the picture, plus a coarse regular grid
+    on_sphere = (a["ids"][::8, ::8, 0] >= fs.n_tri)
+    ys, xs = np.nonzero(on_sphere)
+    assert ys.size >= 4
+    pick = np.linspace(0, ys.size - 1, 4).astype(int)
+    blocks = [(int(xs[i]) * 8, int(ys[i]) * 8) for i in pick] + _blocks(W, H, 2, 2)
+    orc = Oracle(fs)
+    for (x, y) in blocks:
+        ref = orc.render_region(W, H, x, y, 8, 8, mode=_abi.HIPEXEC_MODE_CPU, max_depth=depth, tone=1, n_threads=8, refract=True)
+        assert np.array_equal(a["ids"][y:y + 8, x:x + 8], ref["ids"]), f"hit ids differ in block {(x, y)}"
+        assert_image_parity(a["rgb"][y:y + 8, x:x + 8], ref["rgb"], min_frac=1.0)
+
+
 def test_c5_many_lights_4k_strip():
     """Benchmark config 5 (16 lamps, 16 spheres, 20k triangles) at 3840x2160: one 8-row tile in
     every 9 is rendered (30 tiles), oracle-checked on a grid of blocks inside those tiles."""
