@@ -40,7 +40,14 @@ sys.path.insert(0, ROOT)
 # and their launches serialise; measured on one GPU, rank 0's share of C2 at G = 8: 0.50 ms with four frames in flight and 8
 # queues, 0.48 ms with eight frames and 16 queues; with 4 queues and four frames 13 % slower than with 8 (whole frames: no
 # difference).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1") or 1) >= 4 else "8")
+# (an exported value is raised to what the run wants, never lowered: the GPU boxes export HIP's default of 4)
+_want_queues = 16 if int(os.environ.get("WORLD_SIZE", "1") or 1) >= 4 else 8
+try:
+    _have_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+except ValueError:
+    _have_queues = 0
+if _have_queues < _want_queues:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(_want_queues)
 os.environ.setdefault("HIPEXEC_KNOBS", "1")     # the library honours HIPEXEC_* knobs (HIPEXEC_NO_CULL of the brute-force leg) only with this set
 
 F_TRI, F_SPH = 44.0, 25.0            # algorithmic FLOP per ray-triangle / ray-sphere test of the reference's scans
@@ -368,12 +375,21 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
-    if world > 1 and torch.cuda.device_count() < world:
+    # BENCH_ONE_GPU_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL (whose ranks need a GPU each), to run the N > 1
+    # code path of this file on a box with one GPU.  Its line is marked as a rehearsal and is not a measurement.
+    rehearsal = world > 1 and os.environ.get("BENCH_ONE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearsal else dev          # where the small reductions live (gloo: host tensors)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     builder, kw, W, H, depth, desc = WORKLOADS[args.workload]
     fs = getattr(scenegen, builder)(**kw).to_flat()
@@ -505,7 +521,7 @@ def main(argv=None):
     drain_gather_times()
     rank_diag, diag = diag, None
     lanes = int(st.lanes)
-    per_rank = rank_diag.gather(rank, world, dev) if world > 1 else None
+    per_rank = rank_diag.gather(rank, world, red_dev) if world > 1 else None
 
     # ------------------------------------------------------------------------------------------------------------
     # further legs at N = 1 (hierarchy algorithm): what the headline number is not
@@ -577,7 +593,7 @@ def main(argv=None):
         for e in pipe.ex:
             e.set_camera(fs.cam_pos, fs.cam_mat)
 
-    t = torch.tensor([elapsed, float(agg["rays"]), 1.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(agg["rays"]), 1.0], dtype=torch.float64, device=red_dev)
     if world > 1:
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
@@ -648,7 +664,8 @@ def main(argv=None):
             "metric": "Mrays/sec (primary+secondary)", "value": rays_total / elapsed_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks on one GPU, gloo through host memory: not a measurement",
             "config": {"workload": desc, "width": W, "height": H, "max_depth": depth, "triangles": fs.n_tri,
                        "spheres": fs.n_sph, "lamps": fs.n_lamp, "mode": "cpu-compat (ray_tracer.cpp semantics)",
                        "algorithm": args.algo, "frames_in_flight": in_flight,

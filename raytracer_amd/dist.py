@@ -53,6 +53,11 @@ def gather_frame(local: torch.Tensor, height: int, group=None, dst: int = 0, buf
     if world == 1:
         return deinterleave(local.unsqueeze(0), height)
     rank = dist.get_rank(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only: device buffers go through host memory (the rehearsal of an N > 1 run on a box
+        # with one GPU, all ranks on that GPU; the real path is RCCL and never comes here)
+        frame = gather_frame(local.cpu(), height, group, dst)
+        return frame.to(local.device) if frame is not None else None
     if rank == dst:
         if buf is None:
             buf = gather_buffer(local, group, dst)
