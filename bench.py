@@ -41,12 +41,17 @@ sys.path.insert(0, ROOT)
 # queues, 0.48 ms with eight frames and 16 queues; with 4 queues and four frames 13 % slower than with 8 (whole frames: no
 # difference).
 # (an exported value is raised to what the run wants, never lowered: the GPU boxes export HIP's default of 4)
-_want_queues = 16 if int(os.environ.get("WORLD_SIZE", "1") or 1) >= 4 else 8
+# (whole frames at N = 1 measure the same within 3 % for 4, 8 and 16 queues and 2 to 6 frames in flight, profiles/r03_sweep_queues_in_flight.txt:
+# one GPU keeps the environment's value)
+_world_env = int(os.environ.get("WORLD_SIZE", "1") or 1)
+_want_queues = 16 if _world_env >= 4 else (8 if _world_env >= 2 else 0)
 try:
     _have_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
 except ValueError:
     _have_queues = 0
-if _have_queues < _want_queues:
+if os.environ.get("BENCH_HW_QUEUES"):                       # measurement aid: exactly this many
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["BENCH_HW_QUEUES"]
+elif _have_queues < _want_queues:
     os.environ["GPU_MAX_HW_QUEUES"] = str(_want_queues)
 os.environ.setdefault("HIPEXEC_KNOBS", "1")     # the library honours HIPEXEC_* knobs (HIPEXEC_NO_CULL of the brute-force leg) only with this set
 
