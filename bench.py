@@ -489,11 +489,12 @@ def main(argv=None):
     step(True)
     probe_ms = [float(st.kernel_ms[k]) for k in range(4)]
     dom = max(range(3), key=lambda k: probe_ms[k])
-    agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop", "exec_flop_all")}
+    agg = {k: 0 for k in ("rays", "ms", "launches", "exec_flop", "equiv_flop", "exec_flop_all", "retraced")}
     walk = {"rays": [0, 0, 0], "nodes": [0, 0, 0], "tests": [0, 0, 0], "overflows": 0}      # per ray class: camera, bounce, shadow
 
     def account(s):
         agg["rays"] += s.rays
+        agg["retraced"] += int(s.retraced)
         agg["ms"] += s.kernel_ms[dom]; agg["launches"] += s.launches[dom]
         agg["exec_flop"] += executed_flops_bvh(s, dom, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, dom)
         agg["exec_flop_all"] += sum((executed_flops_bvh(s, k, fs.n_sph) if algo == "bvh" else executed_flops_scan(s, k)) for k in range(3))
@@ -589,10 +590,15 @@ def main(argv=None):
             a = 0.004 * (i + 1)
             ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
             cams.append((fs.cam_pos + np.float32(0.01 * (i + 1)) * np.array([1.0, 0.1, -0.5], np.float32), (fs.cam_mat @ ry).astype(np.float32)))
-        mv = {"rays": 0, "redone": 0}
+        mv = {"rays": 0, "retraced": 0}
+
+        def mv_account(sk):
+            mv["rays"] += sk.rays
+            mv["retraced"] += int(sk.retraced)
         timed_loop(min(args.steps, 2 * in_flight), False, cameras=cams)            # estimates adapt to a moving camera first
-        mv_elapsed = timed_loop(args.steps, False, cameras=cams, on_stats=lambda sk: mv.__setitem__("rays", mv["rays"] + sk.rays))
+        mv_elapsed = timed_loop(args.steps, False, cameras=cams, on_stats=mv_account)
         extra["moving_camera"] = {"ms_per_step": mv_elapsed / args.steps * 1e3, "value": mv["rays"] / mv_elapsed / 1e6, "unit": "Mrays/s",
+                                  "frames_retraced": mv["retraced"],
                                   "note": "the same loop with a new camera before every frame (hipexec_set_camera: 0.23 degrees of orbit and a "
                                           "small dolly per frame); every frame is traced completely"}
         for e in pipe.ex:
@@ -681,6 +687,7 @@ def main(argv=None):
                        "partition": f"interleaved 8-row tiles over {world} GPU(s), gather to rank 0",
                        "rays_per_frame": rays_total / args.steps},
             "frames_rendered": frames_rendered,
+            "frames_retraced": agg["retraced"],      # frames of the timed region traced twice because a launch was sized too small
             "roofline": roof,
         }
         for k in ("single_frame_ms", "first_frame_ms", "moving_camera"):

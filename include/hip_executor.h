@@ -160,7 +160,7 @@ typedef struct hipexec_render_cfg {
  * colours; they differ in which tests they can prove unnecessary. */
 enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };
 
-#define HIPEXEC_ABI_VERSION 5
+#define HIPEXEC_ABI_VERSION 6
 
 /* Kernel classes reported in hipexec_stats. */
 enum {
@@ -205,6 +205,9 @@ typedef struct hipexec_stats {
     uint32_t launches[HIPEXEC_K_COUNT];
     float    kernel_ms[HIPEXEC_K_COUNT];   /* summed HIP-event time, only with HIPEXEC_FLAG_TIME_KERNELS */
     float    total_ms;                     /* HIP-event time of the whole call on its stream */
+    uint32_t retraced;                     /* times the call was traced again because a launch, sized on the host from
+                                              an earlier frame's ray counts, proved smaller than its queue (the results
+                                              and the other fields are the last tracing's); 0 for a frame that repeats */
 } hipexec_stats;
 
 /* One closest-hit result: the `Hit` of scene.h:48-63 plus the identifiers the reference

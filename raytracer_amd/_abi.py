@@ -19,7 +19,7 @@ HIPEXEC_FLAG_REFRACT = 16
 HIPEXEC_FLAG_AO = 32
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATIC_MAX_RAYS = 1 << 18
 
 _fp = C.POINTER(C.c_float)
@@ -56,7 +56,7 @@ class Stats(C.Structure):
         ("tests_tri_any", C.c_uint64), ("tests_sph_any", C.c_uint64),
         ("tests_tri_primary", C.c_uint64), ("exact_groups", C.c_uint64 * 3), ("scanned_chunks", C.c_uint64 * 3),
         ("bvh_nodes", C.c_uint64 * 3), ("bvh_tests", C.c_uint64 * 3), ("bvh_stack_overflows", C.c_uint64), ("algorithm", C.c_uint32), ("lanes", C.c_uint32),
-        ("launches", C.c_uint32 * K_COUNT), ("kernel_ms", C.c_float * K_COUNT), ("total_ms", C.c_float),
+        ("launches", C.c_uint32 * K_COUNT), ("kernel_ms", C.c_float * K_COUNT), ("total_ms", C.c_float), ("retraced", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -71,6 +71,7 @@ class Stats(C.Structure):
         d["launches"] = list(self.launches)
         d["kernel_ms"] = [float(x) for x in self.kernel_ms]
         d["total_ms"] = float(self.total_ms)
+        d["retraced"] = int(self.retraced)
         return d
 
     @property

@@ -289,9 +289,16 @@ constexpr int LV_PER = 68;                                   // level counters p
 struct LevelPred {
     std::array<int64_t, 24> key{};
     std::vector<uint32_t> n;                                  // n[L], L >= 1: queue sizes the last frame with this key produced
-    bool steady = false;                                      // the frame before produced the same sizes
+    // Levels 1..seen were counted by that frame itself (entries past the end of n are true zeros).  A frame that hands
+    // its small deep levels to k_bvh_tail counts only up to the level the tail kernel starts at (the kernel keeps the
+    // later rays to itself); entries above `seen` are then carried over from the last frame that did count them, and
+    // a level of which nothing is known is launched for the bound -- never for "zero rays", which is what made a
+    // frame sized with the margin (too large for the tail kernel at that level) lose the next level's rays and be
+    // traced twice.
+    int seen = 0;
+    bool steady = false;                                      // the frame before produced the same sizes on the levels both counted
 };
-struct LevelCheck { int slot; std::array<int64_t, 24> key; std::vector<uint32_t> launched; };
+struct LevelCheck { int slot; std::array<int64_t, 24> key; std::vector<uint32_t> launched; int tail_level; };
 // How the launches of a batch's levels get their sizes.
 enum { SIZE_AUTO = 0,      // from remembered sizes where they exist, else from the bound
        SIZE_BOUND = 1,     // from the bound n(L+1) <= n(L) only (repeat of a frame; HIPEXEC_PREDICT=2)
@@ -369,6 +376,7 @@ struct hipexec {
     int size_mode = SIZE_AUTO;                // of the call in progress (SIZE_BOUND while a frame is being repeated, SIZE_WAIT for batch calls)
     int predict_spoil = 0;                    // test hook: remembered level-1 sizes are stored this much too large (or too small)
     bool redo = false;                        // a level was launched too small: the frame has to be repeated
+    uint32_t retraced = 0u;                   // 1 while the repeat of such a frame runs (reported in the call's statistics)
     hipexec_render_cfg pending_cfg{};         // arguments of an asynchronous call, for such a repeat
     float4 *pending_rgba = nullptr; int32_t *pending_ids = nullptr;
     unsigned long long *h_cnt64 = nullptr;    // pinned
@@ -888,6 +896,7 @@ void add_stats(hipexec_stats &d, const hipexec_stats &a)
     d.tests_tri_any += a.tests_tri_any; d.tests_sph_any += a.tests_sph_any;
     d.tests_tri_primary += a.tests_tri_primary;
     d.bvh_stack_overflows += a.bvh_stack_overflows;
+    d.retraced += a.retraced;
     for (int k = 0; k < 3; k++) {
         d.exact_groups[k] += a.exact_groups[k]; d.scanned_chunks[k] += a.scanned_chunks[k];
         d.bvh_nodes[k] += a.bvh_nodes[k]; d.bvh_tests[k] += a.bvh_tests[k];
@@ -944,14 +953,26 @@ int call_end(hipexec *h, hipexec_stats *stats)
             h->acc.tests_tri_closest += (uint64_t)got[L] * h->S.n_tri;
             h->acc.tests_sph_closest += (uint64_t)got[L] * h->S.n_sph;
         }
-        LevelPred rec; rec.key = c.key; rec.n.assign(got, got + top + 1); rec.n[0] = 0u;
+        const int seen = c.tail_level >= 0 ? c.tail_level : LV_PER - 1;
+        LevelPred rec; rec.key = c.key; rec.seen = seen; rec.n.assign(got, got + top + 1); rec.n[0] = 0u;
         // test hook: a remembered size that is wrong, so that the check above and the repeat of the frame can be exercised
         if (h->predict_spoil && rec.n.size() > 1 && (int64_t)rec.n[1] + h->predict_spoil > 0)
             rec.n[1] = (uint32_t)((int64_t)rec.n[1] + h->predict_spoil);
         std::lock_guard<std::mutex> lk(h->pred_home->pred_m);
         std::vector<LevelPred> &preds = h->pred_home->preds;
         for (size_t i = 0; i < preds.size(); i++)
-            if (preds[i].key == c.key) { rec.steady = preds[i].n == rec.n; preds.erase(preds.begin() + (long)i); break; }
+            if (preds[i].key == c.key) {
+                const LevelPred &old = preds[i];
+                auto at = [](const std::vector<uint32_t> &v, int L) { return (size_t)L < v.size() ? v[(size_t)L] : 0u; };
+                rec.steady = true;
+                for (int L = 1; L <= std::min(seen, old.seen); L++) rec.steady = rec.steady && at(old.n, L) == at(rec.n, L);
+                if (old.n.size() > (size_t)seen + 1) {        // levels this frame left to the tail kernel: what is known of them stays
+                    rec.n.resize((size_t)seen + 1, 0u);
+                    rec.n.insert(rec.n.end(), old.n.begin() + seen + 1, old.n.end());
+                }
+                preds.erase(preds.begin() + (long)i);
+                break;
+            }
         if (preds.size() >= 64) preds.erase(preds.begin());
         preds.push_back(rec);
     }
@@ -964,6 +985,7 @@ int call_end(hipexec *h, hipexec_stats *stats)
         if (g->redo) { h->redo = true; g->redo = false; }
     }
     h->lanes_used = 1;
+    h->acc.retraced = h->retraced;
     if (stats) *stats = h->acc;
     return HIPEXEC_OK;
 }
@@ -976,6 +998,7 @@ struct LevelRun {
     LevelPred pred;
     std::array<int64_t, 24> key{};
     std::vector<uint32_t> launched;      // launched[L]: size the launches of level L were made for (sized runs)
+    int tail_level = -1;                 // level from which k_bvh_tail took the batch over (-1: it did not)
 };
 
 int level_begin(hipexec *h, const std::array<int64_t, 24> &key, bool may_size, LevelRun &run)
@@ -1012,7 +1035,9 @@ int level_count(hipexec *h, LevelRun &run, int level, uint32_t prev, uint32_t *o
     *counted = !run.sized;
     if (run.sized) {
         uint32_t n = prev;                                              // the bound: at most one successor per ray
-        if (run.have_pred) {
+        // (a level the remembered frame did not count itself is known only from an older frame's entry, and that only
+        // while the counted levels repeat; otherwise nothing is known of it and the bound stands)
+        if (run.have_pred && (level <= run.pred.seen || (run.pred.steady && (size_t)level < run.pred.n.size()))) {
             const uint32_t last = (size_t)level < run.pred.n.size() ? run.pred.n[(size_t)level] : 0u;
             // steady: exactly what the last two frames produced; otherwise an eighth more and a few blocks' worth of slack
             const uint64_t want = run.pred.steady ? last : (uint64_t)last + last / 8u + 4096u;
@@ -1036,7 +1061,7 @@ int level_end(hipexec *h, LevelRun &run)
         // the counts the kernels produced come back with the call and are compared with the launches then (call_end)
         HIPCHK(hipMemcpyAsync(h->h_lvl + (size_t)run.slot * LV_PER, h->d_lvl + (size_t)run.slot * LV_PER, LV_PER * sizeof(uint32_t),
                               hipMemcpyDeviceToHost, h->stream));
-        h->checks.push_back(LevelCheck{run.slot, run.key, run.launched});
+        h->checks.push_back(LevelCheck{run.slot, run.key, run.launched, run.tail_level});
     }
     return HIPEXEC_OK;
 }
@@ -1257,6 +1282,7 @@ int trace_levels_overlapped(hipexec *h, uint32_t n0, size_t stride, int depth, i
         cur_hits = hit_buf[(level + 1) & 1];
         if (use_tail(h, nn, level + 1, depth)) {
             CHK(launch_tail<MODE>(h, cur_rays, nn, level + 1, depth, stride, level_fill(h, run, level + 1)));
+            run.tail_level = level + 1;
             tail = true;
             break;
         }
@@ -1335,6 +1361,7 @@ int trace_levels_run(hipexec *h, uint32_t n0, size_t stride, int max_depth, int 
         }
         if (use_tail(h, nn, level + 1, depth)) {
             CHK(launch_tail<MODE>(h, next_rays, nn, level + 1, depth, stride, level_fill(h, run, level + 1)));
+            run.tail_level = level + 1;
             *levels_used = depth + 1;
             return HIPEXEC_OK;
         }
@@ -1609,9 +1636,9 @@ int run_checked(hipexec *h, F frame)
 {
     int rc = frame();
     if (rc == HIPEXEC_OK && h->redo) {
-        h->redo = false; h->size_mode = SIZE_BOUND;
+        h->redo = false; h->size_mode = SIZE_BOUND; h->retraced = 1u;
         rc = frame();
-        h->size_mode = h->size_default; h->redo = false;
+        h->size_mode = h->size_default; h->redo = false; h->retraced = 0u;
     }
     return rc;
 }
@@ -1937,7 +1964,7 @@ int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int3
     ex[0] = h;
     for (int k = 1; k < K; k++) ex[(size_t)k] = h->prog_clones[(size_t)k - 1];
     const size_t step_bytes = (size_t)tiles_per_step * HIPEXEC_TILE_ROWS * W * 12;
-    const int lanes_saved = h->max_lanes;
+    struct RestoreLanes { hipexec *h; int lanes; ~RestoreLanes() { h->max_lanes = lanes; } } restore_lanes{h, h->max_lanes};
     for (hipexec *e : ex) {
         // the clones follow this executor's camera, algorithm and knobs of the moment
         if (e != h) {
@@ -1988,7 +2015,6 @@ int hipexec_render_progressive(hipexec_t *h, const hipexec_render_cfg *cfg, int3
         if (e->call_open) { (void)hipStreamSynchronize(e->stream); e->call_open = false; }      // after an error: nothing stays in flight
         e->win_lo = 0; e->win_hi = INT_MAX;
     }
-    h->max_lanes = lanes_saved;
     if (rc == HIPEXEC_OK && stats) *stats = total;
     return rc;
 }

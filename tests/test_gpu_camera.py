@@ -164,3 +164,34 @@ def test_clone_of_a_large_texture_set_takes_no_second_copy():
         finally:
             for e in clones:
                 e.close()
+
+
+def test_levels_left_to_the_tail_kernel_are_not_remembered_as_empty(monkeypatch):
+    """k_bvh_tail takes a batch over from the first level whose launch is small enough, and the levels after it are then
+    not counted one by one.  Whether a level is small enough depends on how its launch was sized: with the exact
+    remembered size level 1 is (the knob puts the limit at exactly n(1)), with the margin of a frame that follows a
+    change it is not, and level 2 then gets a launch of its own -- which must be sized from what is known of level 2
+    (an older frame's count, or the bound), not from the zero the tail-kernel frame left.  No frame of the static
+    sequence may be traced twice, and every one is the oracle's."""
+    from oracle.binding import Oracle
+    from raytracer_amd.executor import HipExecutor
+    fs = scenegen.small_variant("c2").to_flat()
+    W, H, depth = 192, 264, 3
+    orc = Oracle(fs)
+    ref = orc.render(W, H, mode=CPU, max_depth=depth, tone=0, n_threads=8)
+    n1 = int(orc.render(W, H, mode=CPU, max_depth=1, tone=0, n_threads=8)["stats"].rays_bounce)
+    n2 = int(orc.render(W, H, mode=CPU, max_depth=2, tone=0, n_threads=8)["stats"].rays_bounce) - n1
+    n0 = W * H * 4
+    # level 1 sized with the margin (capped by the bound n0) is above the limit; level 2 is more than the margin's slack
+    # alone covers, and small enough for the tail kernel either way
+    assert n1 < n0 and n2 > 2 * 4096 and n2 + n2 // 8 + 4096 <= n1, (n0, n1, n2)
+    monkeypatch.setenv("HIPEXEC_KNOBS", "1")
+    monkeypatch.setenv("HIPEXEC_TAIL_MAX", str(n1))
+    retraced = []
+    with HipExecutor(fs, device=0) as ex:
+        ex.set_lanes(1)
+        for i in range(8):
+            got = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
+            _check(got, ref, f"frame {i}")
+            retraced.append(int(got["stats"].retraced))
+    assert retraced == [0] * 8, retraced
