@@ -1,6 +1,6 @@
 #!/bin/bash
-# bench.py lines of every workload for a round's profiles: bash tools/bench_all.sh r02   (GPU box, repository root)
-TAG=${1:-r02}
+# bench.py lines of every workload for a round's profiles: bash tools/bench_all.sh r03   (GPU box, repository root)
+TAG=${1:-r03}
 mkdir -p gpurun_out/bench_$TAG
 for wl in c1 c3 c4 c5; do
   timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-brute 2>/dev/null | grep '^{"metric' > gpurun_out/bench_$TAG/${TAG}_bvh_bench_$wl.json || { echo "$wl failed"; exit 1; }
