@@ -13,7 +13,7 @@ import os
 import shutil
 import sys
 
-MAX_CLOCK_GHZ = 2.6           # a 2.4 GHz part; the margin is the counters' own slow-down of a pass against the trace pass, which runs without them
+MAX_CLOCK_GHZ = 2.6           # a 2.4 GHz part; GUI cycles of a dispatch over its own duration read up to 5 % high on dispatches shorter than 0.3 ms
 
 
 def newest(pattern):
@@ -72,6 +72,7 @@ def main():
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     per_launch = collections.defaultdict(lambda: collections.defaultdict(float))
     pass_frames = {}
+    gui_ns = collections.defaultdict(int)
     for f in newest(f"{src}/pmc_*/*/*counter_collection.csv"):
         which = f.split("/")[2]
         pass_frames[which] = frames_of(which)
@@ -83,6 +84,8 @@ def main():
                 continue
             raw[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k][r["Counter_Name"]] += 1                          # one row per dispatch and counter
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":               # the same dispatches' own durations, for the clock
+                gui_ns[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         for k in raw:
             for name, v in raw[k].items():
                 tot[k][name] += v / pass_frames[which]               # per frame of the pass that collected the counter
@@ -109,9 +112,13 @@ def main():
         if gui:
             m["per_frame_kernel"] = bool(m["launches_per_frame"] and m["launches_per_frame"] >= 1.0)   # else: once per scene (hierarchy build)
             if ms_frame and m["per_frame_kernel"]:
-                m["clock_ghz"] = gui / (ms_frame * 1e6)
-                if m["clock_ghz"] > MAX_CLOCK_GHZ:
-                    raise SystemExit(f"{k}: the counters imply a clock of {m['clock_ghz']:.2f} GHz: frames are miscounted")
+                # GUI cycles per frame of the counter pass over (a) the durations of the same dispatches in that pass: the
+                # clock the chip held; (b) the un-profiled serial durations: the same, times the counter pass's slow-down.
+                # A frame miscount shows in (b) as a factor, not as per cent.
+                m["clock_ghz"] = d["GRBM_GUI_ACTIVE"] * pass_frames["pmc_sq2"] / 8.0 / gui_ns[k] if gui_ns.get(k) else None
+                m["clock_ghz_against_unprofiled_durations"] = gui / (ms_frame * 1e6)
+                if (m["clock_ghz"] or 0) > MAX_CLOCK_GHZ or m["clock_ghz_against_unprofiled_durations"] > 1.25 * MAX_CLOCK_GHZ:
+                    raise SystemExit(f"{k}: the counters imply a clock of {m['clock_ghz']} / {m['clock_ghz_against_unprofiled_durations']:.2f} GHz: frames are miscounted")
             # the SIMDs are 32 lanes wide: with two or more waves resident a SIMD issues one wave64 VALU instruction per
             # 2 cycles (the 157.3 TFLOP/s FP32 peak is that rate), so the fraction of the issue peak is instructions x 2 /
             # SIMD-cycles.  SQ_ACTIVE_INST_VALU (quad-cycles a wave spends in VALU instructions, 4 cycles each for a wave
