@@ -279,9 +279,8 @@ constexpr int LV_PER = 68;                                   // level counters p
 // that is larger than its queue costs only blocks that exit at once.  The sizes come from
 //   * the bound n(L+1) <= n(L) (a ray has at most one successor) when nothing is remembered: first frame of a
 //     configuration, or the repeat of a frame whose sizes proved too small;
-//   * the remembered sizes themselves when the last two frames with this key agreed (a static scene and camera repeat
-//     exactly: rendering is deterministic);
-//   * the remembered sizes plus a margin, capped by the bound, otherwise (a moving camera).
+//   * otherwise the sizes the last frame with this key produced plus a margin (a quarter, twice the change from the
+//     frame before that, 4096 rays), capped by the bound: a frame that repeats and a camera that moves are sized alike.
 // The sizes the kernels produced come back with the frame and are compared with what was launched when the call is
 // collected: only a level that was launched too SMALL has lost rays, and only then the frame is traced again (from
 // the bound, which cannot be too small).  Decisions that depend on a launch size (threads per block, tail kernel,
@@ -296,6 +295,7 @@ struct LevelPred {
     // frame sized with the margin (too large for the tail kernel at that level) lose the next level's rays and be
     // traced twice.
     int seen = 0;
+    std::vector<uint32_t> delta;                              // delta[L]: by how much n[L] differed from the frame before (levels both counted)
     bool steady = false;                                      // the frame before produced the same sizes on the levels both counted
 };
 struct LevelCheck { int slot; std::array<int64_t, 24> key; std::vector<uint32_t> launched; int tail_level; };
@@ -947,7 +947,15 @@ int call_end(hipexec *h, hipexec_stats *stats)
             covered = covered && got[L] <= launched;
             if (got[L]) top = L;
         }
-        if (!covered) { h->redo = true; continue; }
+        if (!covered) {
+            h->redo = true;
+            if (knob("HIPEXEC_TRACE_REDO"))                  // which level outgrew its launch, and by how much
+                for (int L = 1; L < LV_PER; L++) {
+                    const uint32_t launched = (size_t)L < c.launched.size() ? c.launched[(size_t)L] : 0u;
+                    if (got[L] || launched) fprintf(stderr, "hipexec: level %d launched for %u rays, queue held %u%s\n", L, launched, got[L], got[L] > launched ? "  <-- too small" : "");
+                }
+            continue;
+        }
         for (int L = 1; L <= top; L++) {
             h->acc.rays_bounce += got[L];
             h->acc.tests_tri_closest += (uint64_t)got[L] * h->S.n_tri;
@@ -965,7 +973,13 @@ int call_end(hipexec *h, hipexec_stats *stats)
                 const LevelPred &old = preds[i];
                 auto at = [](const std::vector<uint32_t> &v, int L) { return (size_t)L < v.size() ? v[(size_t)L] : 0u; };
                 rec.steady = true;
-                for (int L = 1; L <= std::min(seen, old.seen); L++) rec.steady = rec.steady && at(old.n, L) == at(rec.n, L);
+                rec.delta = old.delta;
+                rec.delta.resize(std::max(rec.n.size(), old.n.size()), 0u);
+                for (int L = 1; L <= std::min(seen, old.seen); L++) {
+                    const uint32_t a = at(old.n, L), b = at(rec.n, L);
+                    rec.steady = rec.steady && a == b;
+                    if ((size_t)L < rec.delta.size()) rec.delta[(size_t)L] = a > b ? a - b : b - a;
+                }
                 if (old.n.size() > (size_t)seen + 1) {        // levels this frame left to the tail kernel: what is known of them stays
                     rec.n.resize((size_t)seen + 1, 0u);
                     rec.n.insert(rec.n.end(), old.n.begin() + seen + 1, old.n.end());
@@ -1039,8 +1053,13 @@ int level_count(hipexec *h, LevelRun &run, int level, uint32_t prev, uint32_t *o
         // while the counted levels repeat; otherwise nothing is known of it and the bound stands)
         if (run.have_pred && (level <= run.pred.seen || (run.pred.steady && (size_t)level < run.pred.n.size()))) {
             const uint32_t last = (size_t)level < run.pred.n.size() ? run.pred.n[(size_t)level] : 0u;
-            // steady: exactly what the last two frames produced; otherwise an eighth more and a few blocks' worth of slack
-            const uint64_t want = run.pred.steady ? last : (uint64_t)last + last / 8u + 4096u;
+            // a quarter more than the last frame produced, twice the last change (a moving camera changes a level's queue
+            // by about as much from frame to frame; the deep levels of a depth-5 frame grew by 18 % over the three frames
+            // a loop with three frames in flight looks back) and a few blocks' worth of slack.  A launch that is too
+            // large costs blocks that exit at once (0.5 ns each), so a frame that repeats is sized the same way: the first
+            // frame after a camera starts to move then still fits.
+            const uint32_t moved = (size_t)level < run.pred.delta.size() ? run.pred.delta[(size_t)level] : 0u;
+            const uint64_t want = (uint64_t)last + last / 4u + 2ull * moved + 4096u;
             n = (uint32_t)std::min<uint64_t>(prev, want);
         }
         run.launched.resize((size_t)level + 1, 0u);

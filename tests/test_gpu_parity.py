@@ -367,12 +367,13 @@ def test_sub_rectangles_equal_the_frame_and_the_oracle(backends, mode, depth):
                                               walk.ctypes.data, None, None))
 
 
-@pytest.mark.parametrize("spoil", ["0", "64", "-64", "off", "bound"])
+@pytest.mark.parametrize("spoil", ["0", "64", "-9000", "off", "bound"])
 def test_remembered_queue_sizes(monkeypatch, spoil):
     """The launches of the recursion levels are sized on the host: from the bound n(L+1) <= n(L) in the first frame of a
     configuration, from the queue sizes the last frame produced afterwards, never waiting for a count; the produced
     counts are checked when the call is collected.  HIPEXEC_PREDICT_SPOIL stores wrong sizes: too large is harmless,
-    too small loses rays on the device, which the check must catch (the frame is then traced again from the bound);
+    too small by more than the margin (-9000 of level 1's 25 344 rays) loses rays on the device, which the check must
+    catch (the frame is then traced again from the bound, and the call's statistics say so);
     the frame must come out right all the same.  HIPEXEC_PREDICT=0 always waits for the counts, =2 always sizes from
     the bound.  Synchronous, sharded and asynchronous (device-resident) frames against the oracle, three frames each."""
     from raytracer_amd.executor import HipExecutor
@@ -389,12 +390,16 @@ def test_remembered_queue_sizes(monkeypatch, spoil):
     d_out = hip.malloc(((H + 7) // 8) * 8 * W * 16)
     try:
         with HipExecutor(fs, device=0) as ex:
+            retraced = []
             for _ in range(3):
                 got = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
                 assert np.array_equal(got["ids"], ref["ids"])
                 assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4
                 for k in ("rays_primary", "rays_bounce", "rays_shadow"):
                     assert getattr(got["stats"], k) == getattr(ref["stats"], k), k
+                retraced.append(int(got["stats"].retraced))
+            # the first frame has nothing remembered and is sized from the bound; the spoiled memory shows from the second on
+            assert retraced == ([0, 1, 1] if spoil == "-9000" else [0, 0, 0]), retraced
             first = got["rgb"].copy()
             for _ in range(3):                                  # two interleaved shards, each with sizes of its own
                 img = np.zeros((H, W, 3), np.float32)
