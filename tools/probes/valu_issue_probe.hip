@@ -63,6 +63,30 @@ KERNEL(k_cmp3, F_CMP3, 8)
 KERNEL(k_cmp1, F_CMP1, 8)
 KERNEL(k_exec, F_EXEC, 6)
 
+
+// packed FP32 (two lanes' worth of work per instruction: the scan kernels' filter): accumulators are register pairs
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define F_PKFMA "v_pk_fma_f32 %0, %8, %9, %0\n v_pk_fma_f32 %1, %8, %9, %1\n v_pk_fma_f32 %2, %8, %9, %2\n v_pk_fma_f32 %3, %8, %9, %3\n" \
+                "v_pk_fma_f32 %4, %8, %9, %4\n v_pk_fma_f32 %5, %8, %9, %5\n v_pk_fma_f32 %6, %8, %9, %6\n v_pk_fma_f32 %7, %8, %9, %7\n"
+#define F_PKMUL "v_pk_mul_f32 %0, %8, %0\n v_pk_mul_f32 %1, %8, %1\n v_pk_mul_f32 %2, %8, %2\n v_pk_mul_f32 %3, %8, %3\n" \
+                "v_pk_mul_f32 %4, %8, %4\n v_pk_mul_f32 %5, %8, %5\n v_pk_mul_f32 %6, %8, %6\n v_pk_mul_f32 %7, %8, %7\n"
+#define KERNEL2(NAME, BODY)                                                                                      \
+__global__ __launch_bounds__(1024) void NAME(float *out, unsigned long long *cyc, float x, float y, float s)     \
+{                                                                                                                \
+    v2f a0 = {(float)threadIdx.x, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
+    v2f vx = {x + threadIdx.x * 1e-9f, x}, vy = {y, y};                                                          \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                        \
+    for (int i = 0; i < ITER; i++)                                                                               \
+        asm volatile(REP4(BODY) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                     : "v"(vx), "v"(vy), "s"(s) : "vcc", "scc");                                                 \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                        \
+    v2f t = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                                               \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t.x + t.y;                                                      \
+    if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;                    \
+}
+KERNEL2(k_pkfma, F_PKFMA)
+KERNEL2(k_pkmul, F_PKMUL)
+
 typedef void (*kern_t)(float *, unsigned long long *, float, float, float);
 
 int main()
@@ -72,7 +96,8 @@ int main()
         {"v_fma_f32 v,v,v", k_fma, 8, 0}, {"v_add_f32 v,v", k_add, 8, 0}, {"v_add_f32 |v|, s (VOP3, abs, SGPR)", k_addabs_s, 8, 0},
         {"v_sub_f32 s, v (VOP2, SGPR)", k_sub_s, 8, 0}, {"v_fma_f32 -v,|v|,v", k_fmaabs, 8, 0}, {"v_max3_f32", k_max3, 8, 0},
         {"v_cmp vcc + v_cndmask", k_cmpv, 8, 0}, {"3 v_cmp + 2 s_and + v_cndmask", k_cmp3, 8, 4}, {"v_max, v_min, v_cmp, v_cndmask", k_cmp1, 8, 0},
-        {"v_cmp, s_and_saveexec, v_add, s_or exec", k_exec, 4, 4}};
+        {"v_cmp, s_and_saveexec, v_add, s_or exec", k_exec, 4, 4},
+        {"v_pk_fma_f32 (counted once)", k_pkfma, 8, 0}, {"v_pk_mul_f32 (counted once)", k_pkmul, 8, 0}};
     // w waves per SIMD on every CU: blocks of 256 * w threads (a block's waves are spread over the CU's four SIMDs) with
     // enough dynamic LDS that one block (w <= 4) or two (w = 6, 8) fit a CU, one or two blocks per CU in the grid
     struct Cfg { int w, threads, lds, blocks; } cfgs[] = {{1, 256, 100 << 10, 256}, {2, 512, 100 << 10, 256}, {3, 768, 100 << 10, 256},
