@@ -422,13 +422,15 @@ DEV f3 ao_ray(f3 P, f3 realNorm, uint32_t i) {
 // Whole-number exponents up to 1024 (a specular hardness as Blender exports it is an integer from 1 to 511) take
 // square-and-multiply in double: at most 20 multiplications, within 3e-15 relative of the power, so the rounding to
 // float differs from the correctly rounded result only where the generic evaluation in double could as well.
-DEV float pow_cr(float x, float y) {
+DEV bool pow_whole_exponent(float y) { int n = (int)y; return (float)n == y && n >= 0 && n <= 1024; }
+DEV float pow_whole(float x, float y) {          // for exponents that pow_whole_exponent accepts
     int n = (int)y;
-    if ((float)n == y && n >= 0 && n <= 1024) {
-        double b = (double)x, r = 1.0;
-        for (; n; n >>= 1) { if (n & 1) r *= b; b *= b; }
-        return (float)r;
-    }
+    double b = (double)x, r = 1.0;
+    for (; n; n >>= 1) { if (n & 1) r *= b; b *= b; }
+    return (float)r;
+}
+DEV float pow_cr(float x, float y) {
+    if (pow_whole_exponent(y)) return pow_whole(x, y);
     return (float)pow((double)x, (double)y);
 }
 
@@ -444,7 +446,11 @@ DEV bool casts_shadow_ray(float dotWithDir, float dotWithLamp) {
 
 // contribution of one unoccluded lamp, added to `ret` in the reference's order:
 // ray_tracer.cpp:185-187,376-403 / ray_tracer_cl.cpp:159-174
-template <int MODE>
+// WHOLE: the caller has checked that the hardness is a whole-number exponent (pow_whole_exponent) for every lane that
+// gets here, and the generic double-precision pow is left out of the code: inlined into a lamp loop, its two dozen
+// 64-bit constants are hoisted in front of the loop and from there into scratch memory (ten 8-byte stores per sample,
+// 0.9 GB of HBM writes per C2 frame), although hardly a scene has a fractional hardness.
+template <int MODE, bool WHOLE = false>
 DEV f3 add_lamp(f3 ret, const Surf &sf, f3 d, f3 toLamp, float intensity, float distance) {
     float dd = fabsf(dot(sf.N, toLamp));
     float sqrLength = dot(toLamp, toLamp);
@@ -452,14 +458,14 @@ DEV f3 add_lamp(f3 ret, const Surf &sf, f3 d, f3 toLamp, float intensity, float 
     float sd = dot(refl, d);
     if (MODE == HIPEXEC_MODE_CL) {
         ret = ret + ((((sf.color * sf.kd) * intensity) * distance) * dd) / sqrLength;
-        float k = (sf.hard * distance / dot(toLamp, toLamp)) * pow_cr(sd, sf.hard);
+        float k = (sf.hard * distance / dot(toLamp, toLamp)) * (WHOLE ? pow_whole(sd, sf.hard) : pow_cr(sd, sf.hard));
         float spec = (0.0f < k) ? k : 0.0f;
         ret = ret + (sf.color * sf.ks) * spec;
     } else {
         float diff = intensity * distance * dd / sqrLength;
         ret = ret + (sf.color * sf.kd) * diff;
         float phong = 0.0f;
-        if (sd > 0.0f) phong = (sf.hard * distance / dot(toLamp, toLamp)) * pow_cr(sd, sf.hard);
+        if (sd > 0.0f) phong = (sf.hard * distance / dot(toLamp, toLamp)) * (WHOLE ? pow_whole(sd, sf.hard) : pow_cr(sd, sf.hard));
         ret = ret + (sf.color * sf.ks) * phong;
     }
     return ret;

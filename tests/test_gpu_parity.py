@@ -546,3 +546,25 @@ def test_executors_made_from_pooled_memory_render_the_same_frames():
         if round_ == 1:
             executor.trim()                                            # everything cached goes back to the driver
     executor.trim(0)
+
+
+@pytest.mark.parametrize("hard", [(12.5, 50.0, 7.25), (0.0, 1.0, 1024.0), (1500.0, 1025.0, 3.0), (0.5, 0.5, 0.5)])
+@pytest.mark.parametrize("algo", ["bvh", "scan"])
+def test_specular_exponents_whole_fractional_and_large(algo, hard):
+    """powf(sd, hardness) of the Phong term (ray_tracer.cpp:396-401, ray_tracer_cl.cpp:166-171): whole-number exponents up to
+    1024 take a multiplication chain on the device, everything else the generic evaluation, and the kernels that shade
+    after tracing carry two copies of their lamp loop, chosen per wave by whether all of its samples have whole-number
+    exponents.  Materials with mixed exponents put both kinds into one wave; each combination against the oracle's frame."""
+    from oracle.binding import Oracle
+    from raytracer_amd.executor import HipExecutor
+    fs = scenegen.small_variant("c2").to_flat()
+    fs.mat_hard = [float(hard[i % 3]) for i in range(len(fs.mat_hard))]
+    fs.mat_ks = [0.9 for _ in fs.mat_ks]
+    W, H, depth = 64, 56, 2
+    orc = Oracle(fs)
+    with HipExecutor(fs, device=0) as ex:
+        for mode in (CPU, CL):
+            ref = orc.render(W, H, mode=mode, max_depth=depth, tone=0, n_threads=8)
+            got = ex.render(W, H, mode=mode, max_depth=depth, tone=False, algo=algo)
+            assert np.array_equal(got["ids"], ref["ids"])
+            assert ulp_diff(got["rgb"], ref["linear"]).max() <= 4, (mode, ulp_diff(got["rgb"], ref["linear"]).max())
