@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
             load_ray(rays, j, o, d, s, aux);
             float4 hh = hits[j];
             if (__float_as_int(hh.w) >= -1)
-                local[s] = shade_sample<MODE, true>(S, o, d, hh, &occ_lds[tid], spawn != 0, bounce, bo, bd);
+                local[s] = shade_sample<MODE>(S, o, d, hh, &occ_lds[tid], spawn != 0, bounce, bo, bd);
         }
         if (spawn && next_rays) {
             __shared__ uint32_t append_scratch[5];
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
             load_ray(rays, j, o, d, s, aux);
             float4 hh = hits[j];
             if (__float_as_int(hh.w) >= -1)
-                local[s] = shade_sample<MODE, true>(S, o, d, hh, &occ_bits, spawn != 0, bounce, bo, bd, ao);
+                local[s] = shade_sample<MODE>(S, o, d, hh, &occ_bits, spawn != 0, bounce, bo, bd, ao);
         }
         if (spawn && next_rays) {
             __shared__ uint32_t append_scratch[5];

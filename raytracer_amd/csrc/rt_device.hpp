@@ -429,9 +429,15 @@ DEV float pow_whole(float x, float y) {          // for exponents that pow_whole
     for (; n; n >>= 1) { if (n & 1) r *= b; b *= b; }
     return (float)r;
 }
+// The generic evaluation is a function of its own, never inlined: inlined into a lamp loop, its two dozen 64-bit
+// polynomial constants are hoisted in front of the loop and, in the kernels that shade after tracing and are short of
+// registers, from there into scratch memory (ten 8-byte stores per sample on every path, 0.9 GB of HBM writes per C2
+// frame), although hardly a scene has a fractional hardness.  As a call on the rare path it costs the common one nothing:
+// k_bvh_shadow_direct 80 VGPRs + 18 spilled -> 76 and none, k_shade 96 -> 76, k_bvh_tail 42 spilled -> 4.
+__device__ __attribute__((noinline)) float pow_generic(float x, float y) { return (float)pow((double)x, (double)y); }
 DEV float pow_cr(float x, float y) {
     if (pow_whole_exponent(y)) return pow_whole(x, y);
-    return (float)pow((double)x, (double)y);
+    return pow_generic(x, y);
 }
 
 // facing test that decides whether a shadow ray is cast:
@@ -446,11 +452,7 @@ DEV bool casts_shadow_ray(float dotWithDir, float dotWithLamp) {
 
 // contribution of one unoccluded lamp, added to `ret` in the reference's order:
 // ray_tracer.cpp:185-187,376-403 / ray_tracer_cl.cpp:159-174
-// WHOLE: the caller has checked that the hardness is a whole-number exponent (pow_whole_exponent) for every lane that
-// gets here, and the generic double-precision pow is left out of the code: inlined into a lamp loop, its two dozen
-// 64-bit constants are hoisted in front of the loop and from there into scratch memory (ten 8-byte stores per sample,
-// 0.9 GB of HBM writes per C2 frame), although hardly a scene has a fractional hardness.
-template <int MODE, bool WHOLE = false>
+template <int MODE>
 DEV f3 add_lamp(f3 ret, const Surf &sf, f3 d, f3 toLamp, float intensity, float distance) {
     float dd = fabsf(dot(sf.N, toLamp));
     float sqrLength = dot(toLamp, toLamp);
@@ -458,14 +460,14 @@ DEV f3 add_lamp(f3 ret, const Surf &sf, f3 d, f3 toLamp, float intensity, float 
     float sd = dot(refl, d);
     if (MODE == HIPEXEC_MODE_CL) {
         ret = ret + ((((sf.color * sf.kd) * intensity) * distance) * dd) / sqrLength;
-        float k = (sf.hard * distance / dot(toLamp, toLamp)) * (WHOLE ? pow_whole(sd, sf.hard) : pow_cr(sd, sf.hard));
+        float k = (sf.hard * distance / dot(toLamp, toLamp)) * pow_cr(sd, sf.hard);
         float spec = (0.0f < k) ? k : 0.0f;
         ret = ret + (sf.color * sf.ks) * spec;
     } else {
         float diff = intensity * distance * dd / sqrLength;
         ret = ret + (sf.color * sf.kd) * diff;
         float phong = 0.0f;
-        if (sd > 0.0f) phong = (sf.hard * distance / dot(toLamp, toLamp)) * (WHOLE ? pow_whole(sd, sf.hard) : pow_cr(sd, sf.hard));
+        if (sd > 0.0f) phong = (sf.hard * distance / dot(toLamp, toLamp)) * pow_cr(sd, sf.hard);
         ret = ret + (sf.color * sf.ks) * phong;
     }
     return ret;

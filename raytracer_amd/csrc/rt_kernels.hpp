@@ -918,9 +918,7 @@ __global__ __launch_bounds__(256) void k_shadowgen(DScene S, const float4 *__res
 // with a bounce ray (returned in bo, bd) and -1 otherwise (ray_tracer.cpp:165-199 /
 // ray_tracer_cl.cpp:119-174).  `occ` points at the sample's occlusion words (bit l: lamp l is hidden).
 // ---------------------------------------------------------------------------------------
-// SPLIT: two copies of the lamp loop, see below (for the kernels that shade after tracing and are short of registers;
-// k_shade alone has room for the generic pow's constants and is 8 % slower with two copies).
-template <int MODE, bool SPLIT = false>
+template <int MODE>
 DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *occ, bool spawn, bool &bounce, f3 &bo, f3 &bd,
                         float ao = 0.0f)
 {
@@ -933,28 +931,14 @@ DEV float4 shade_sample(const DScene &S, f3 o, f3 d, float4 h, const uint32_t *o
         Surf sf = surface(S, o, d, h, true);
         ret = (MODE == HIPEXEC_MODE_CL) ? mk(0.f, 0.f, 0.f) : mk(S.ambient[0], S.ambient[1], S.ambient[2]);
         if (MODE == HIPEXEC_MODE_CPU && S.ao) ret = ret + sf.color * ao;           // ray_tracer.cpp:167-169
-        // two copies of the lamp loop: the one every wave takes whose samples all have a whole-number hardness carries
-        // no generic pow (see add_lamp); per lane both evaluate the same expression
-        if (SPLIT && __ballot(!pow_whole_exponent(sf.hard)) == 0ull) {
-            for (uint32_t l = 0; l < S.n_lamp; l++) {
-                float4 lp = S.lamp[l];
-                f3 toLamp = xyz(lp) - sf.P;
-                float dotWithLamp = dot(toLamp, sf.N);
-                float dotWithDir = dot(d, sf.N);
-                if (!casts_shadow_ray<MODE>(dotWithDir, dotWithLamp)) continue;
-                if (occ[l >> 5] & (1u << (l & 31u))) continue;
-                ret = add_lamp<MODE, true>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
-            }
-        } else {
-            for (uint32_t l = 0; l < S.n_lamp; l++) {
-                float4 lp = S.lamp[l];
-                f3 toLamp = xyz(lp) - sf.P;
-                float dotWithLamp = dot(toLamp, sf.N);
-                float dotWithDir = dot(d, sf.N);
-                if (!casts_shadow_ray<MODE>(dotWithDir, dotWithLamp)) continue;
-                if (occ[l >> 5] & (1u << (l & 31u))) continue;
-                ret = add_lamp<MODE, false>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
-            }
+        for (uint32_t l = 0; l < S.n_lamp; l++) {
+            float4 lp = S.lamp[l];
+            f3 toLamp = xyz(lp) - sf.P;
+            float dotWithLamp = dot(toLamp, sf.N);
+            float dotWithDir = dot(d, sf.N);
+            if (!casts_shadow_ray<MODE>(dotWithDir, dotWithLamp)) continue;
+            if (occ[l >> 5] & (1u << (l & 31u))) continue;
+            ret = add_lamp<MODE>(ret, sf, d, toLamp, lp.w, S.lamp_dist[l]);
         }
         if (MODE == HIPEXEC_MODE_CPU && spawn && secondary_ray(S, sf.mat, sf.kr, d, sf.N, w, bd)) {
             bounce = true;
