@@ -408,7 +408,7 @@ struct hipexec {
     bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
-    uint32_t shadow_waves6_from = 2u;         // HIPEXEC_SHADOW_WAVES6_FROM: lamps from which the shadow kernel compiled for 6 waves per SIMD is used
+    uint32_t shadow_waves6_from = 1u;         // HIPEXEC_SHADOW_WAVES6_FROM: lamps from which the shadow kernel compiled for RT_SHADOW_WAVES_MANY waves per SIMD is used (one lamp, C4: -2 % against the five-wave variant)
     uint32_t simple_from = 0u;                // HIPEXEC_SIMPLE_FROM: closest-hit launches of at least this many rays take one ray per lane
                                               // (k_bvh_closest); smaller ones the kernel whose lanes fetch a new ray when theirs is decided
     bool shadow_direct = true;                // HIPEXEC_SHADOW_DIRECT=0: shadow rays through the block's list in LDS (k_bvh_shadow)
@@ -1232,12 +1232,12 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
         else
             LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256, true>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
                       h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
-    } else if (direct && h->S.n_lamp >= h->shadow_waves6_from) {          // many lamps: the variant compiled for six waves per SIMD
+    } else if (direct && h->S.n_lamp >= h->shadow_waves6_from) {          // the variant compiled for RT_SHADOW_WAVES_MANY waves per SIMD
         if (one_wave)
-            LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64, false, 6>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
+            LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64, false, RT_SHADOW_WAVES_MANY>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,
                       h->occl.as<uint32_t>(), h->lamp_words, h->d_cnt64, 64u, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
         else
-            LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256, false, 6>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
+            LAUNCH_ON(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 256, false, RT_SHADOW_WAVES_MANY>), blocks, h->S, h->B, rays, hits, n, h->occl.as<uint32_t>(),
                       h->lamp_words, h->d_cnt64, per_block, nodes_sc, local_level, (int)spawn, next_rays, next_count, n_dev);
     } else if (direct && one_wave)
         LAUNCH_BS(stream, HIPEXEC_K_ANYHIT, (k_bvh_shadow_direct<MODE, FUSED, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, hits, n,

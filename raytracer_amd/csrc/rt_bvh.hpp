@@ -34,7 +34,7 @@ constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
 constexpr int BVH_LEAF_MAX = 2;
 #ifndef RT_BVH_STACK
-#define RT_BVH_STACK 22
+#define RT_BVH_STACK 21
 #endif
 #ifndef RT_CLOSEST_WAVES
 #define RT_CLOSEST_WAVES 7
@@ -47,6 +47,9 @@ constexpr int BVH_LEAF_MAX = 2;
 #endif
 #ifndef RT_BOX_ONE_CMP
 #define RT_BOX_ONE_CMP 1                        // 0: the box test decides with three comparisons, see bvh_box
+#endif
+#ifndef RT_SHADOW_WAVES_MANY
+#define RT_SHADOW_WAVES_MANY 7                  // waves per SIMD the shadow kernel is compiled for from two lamps up, see k_bvh_shadow_direct
 #endif
 #ifndef RT_BVH_SPLIT_LEAVES
 #define RT_BVH_SPLIT_LEAVES 0                   // 1: free slots of a node are filled by opening its two-triangle leaves, see k_bvh_emit
@@ -1173,9 +1176,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // ---------------------------------------------------------------------------------------
 // AO: the kernel also traces the occlusion rays of HIPEXEC_FLAG_AO (a variant of its own, so that the default kernel does
 // not carry that loop's registers)
-// WAVES: waves per SIMD the kernel is compiled for: 5 (96 VGPRs) for one lamp, 6 (80 VGPRs, 25 values in scratch around the
-// lamp loop, none inside the traversal loop) from two lamps up: the kernel is then a run of traversals whose latency is
-// worth the sixth wave (C5, 16 lamps: -5 %; C2 / C3, 2 lamps: -0.7 %; C4, 1 lamp: +0.5 % at 6).
+// WAVES: waves per SIMD the kernel is compiled for: RT_SHADOW_WAVES_MANY = 7 (72 VGPRs, nothing spilled since the generic
+// pow of the shading is a call; seven blocks' stacks of 21 entries fit a CU's LDS) for the kernels of whole frames (7
+// against 6: C2 -2.3 %, C3 -2.2 %, C5 -3.9 % per frame, C4 with its one lamp -2 % against 5; 8 waves with an 18-entry
+// stack spill and lose all of it again; while the shading still spilled the pow's constants, 7 had measured +-0); the
+// default of 5 (96 VGPRs) remains for the ambient-occlusion variant and the HIPEXEC_SHADOW_WAVES6_FROM knob.
 template <int MODE, bool FUSED, int BS, bool AO = false, int WAVES = RT_SHADOW_WAVES>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_bvh_shadow_direct(DScene S, DBvh B, const float4 *__restrict__ rays,
                                                     const float4 *__restrict__ hits, uint32_t n,
