@@ -614,6 +614,11 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             // the records of the first two triangles are requested together (the array is padded by one record), so a
             // two-triangle leaf waits for memory once
             float4 q[6];
+            // The lane's next node, unless this leaf ends its ray, is the top of its stack: read now, the LDS round trip
+            // passes while the triangle records arrive instead of after the tests (C2 -0.8 %, C3 -1.1 %, C5 -2.1 %; the
+            // same early read in every inner-node step, or in the leaf step of the packets, whose scalar loads share
+            // the wait with it, is slower).
+            const uint32_t below = sp > 0 ? stk[BS * (sp - 1)] : BVH_NONE;
 #pragma unroll
             for (int i = 0; i < 6; i++) q[i] = T[3 * (size_t)first + i];
             for (uint32_t k = first; k < first + cnt; k++) {
@@ -633,8 +638,7 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
                 }
             }
             if (ANY && found) node = BVH_NONE;
-            else if (sp > 0) { sp--; node = stk[BS * sp]; }
-            else node = BVH_NONE;
+            else { node = below; sp = sp > 0 ? sp - 1 : 0; }
         }
     }
     st.node = node; st.sp = sp; st.limit = limit; st.found = found; st.overflow = overflow;
