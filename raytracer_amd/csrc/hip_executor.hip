@@ -405,7 +405,7 @@ struct hipexec {
     hipStream_t side = nullptr;
     hipEvent_t ev_hits[2] = {nullptr, nullptr}, ev_lit[2] = {nullptr, nullptr};
     int fuse_shade = 1;                       // HIPEXEC_FUSE_SHADE: 0 k_shade always a launch of its own, 1 by batch, 2 always fused
-    bool uniform_fetch = true;                // HIPEXEC_UNIFORM_FETCH=0: every inner-node step of the shadow rays fetches per lane
+    uint32_t uniform_fetch = 3u;              // HIPEXEC_UNIFORM_FETCH: bit 0 shadow rays, bit 1 bounce and batch closest-hit rays; a clear bit = every inner-node step of that class fetches per lane
     bool packet = true;                       // HIPEXEC_PACKET=0: per-lane traversal for camera rays too
     bool fuse_raygen = true;                  // HIPEXEC_FUSE_RAYGEN=0: camera rays from k_raygen, a launch of its own
     uint32_t shadow_waves6_from = 1u;         // HIPEXEC_SHADOW_WAVES6_FROM: lamps from which the shadow kernel compiled for RT_SHADOW_WAVES_MANY waves per SIMD is used (one lamp, C4: -2 % against the five-wave variant)
@@ -1148,12 +1148,16 @@ int launch_bvh_closest(hipexec *h, int klass_time, const float4 *rays, uint32_t 
         LAUNCH(klass_time, (k_bvh_closest_p<MODE>), blocks, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count,
                h->refill_closest | (h->sched_w << 8) | (int)(per_block << 16), n_dev);
     } else {
+        // the node array once more as a restrict-qualified argument: steps in which every lane of a wave sits on the same
+        // node (the top of the tree for any rays that start together) fetch the record through the scalar cache and leave
+        // the texture addressers, 74 % busy in this kernel, to the steps whose lanes have spread out
+        const float4 *closest_sc = (h->uniform_fetch & 2u) ? h->B.nodes : nullptr;
         if (h->block_closest == 64 || n <= h->block64_below)
-            LAUNCH_BS(h->stream, klass_time, (k_bvh_closest<MODE, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
+            LAUNCH_BS(h->stream, klass_time, (k_bvh_closest<MODE, 64>), (n + 63u) / 64u, 64, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev, closest_sc);
         else if (h->block_closest == 128)
-            LAUNCH_BS(h->stream, klass_time, (k_bvh_closest<MODE, 128>), (n + 127u) / 128u, 128, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
+            LAUNCH_BS(h->stream, klass_time, (k_bvh_closest<MODE, 128>), (n + 127u) / 128u, 128, h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev, closest_sc);
         else
-            LAUNCH(klass_time, (k_bvh_closest<MODE, 256>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev);
+            LAUNCH(klass_time, (k_bvh_closest<MODE, 256>), blocks_for(n), h->S, h->B, rays, n, hits, h->d_cnt64, klass_count, n_dev, closest_sc);
     }
     return HIPEXEC_OK;
 }
@@ -1222,7 +1226,7 @@ int launch_bvh_shadow(hipexec *h, hipStream_t stream, const float4 *rays, const 
 {
     const uint32_t per_block = small_launch_share(n, h->shadow_per_block);
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    const float4 *nodes_sc = h->uniform_fetch ? h->B.nodes : nullptr;
+    const float4 *nodes_sc = (h->uniform_fetch & 1u) ? h->B.nodes : nullptr;
     const bool direct = h->shadow_direct || h->S.ao;       // the occlusion rays of HIPEXEC_FLAG_AO exist in the direct form only
     const bool one_wave = h->block_shadow == 64 || n <= h->block64_below;
     if (direct && h->S.ao && FUSED && MODE == HIPEXEC_MODE_CPU) {
@@ -1621,7 +1625,7 @@ int create_lane_resources(hipexec *h, uint32_t n_lamp)
     if (const char *e = knob("HIPEXEC_PACKET")) h->packet = atoi(e) != 0;
     if (const char *e = knob("HIPEXEC_FUSE_RAYGEN")) h->fuse_raygen = atoi(e) != 0;
     if (const char *e = knob("HIPEXEC_FUSE_SHADE")) h->fuse_shade = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = knob("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = atoi(e) != 0;
+    if (const char *e = knob("HIPEXEC_UNIFORM_FETCH")) h->uniform_fetch = (uint32_t)atoi(e) & 3u;
     if (const char *e = knob("HIPEXEC_SHADOW_WAVES6_FROM")) h->shadow_waves6_from = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = knob("HIPEXEC_SIMPLE_FROM")) h->simple_from = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = knob("HIPEXEC_SHADOW_DIRECT")) h->shadow_direct = atoi(e) != 0;

@@ -950,7 +950,7 @@ DEV void bvh_count(unsigned long long *counters, int klass, uint32_t n_nodes, ui
 template <int MODE, int BS>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(RT_CLOSEST_WAVES))) void k_bvh_closest(DScene S, DBvh B, const float4 *__restrict__ rays, uint32_t n,
                                                      float4 *__restrict__ hits, unsigned long long *__restrict__ counters,
-                                                     int klass, const uint32_t *__restrict__ n_dev)
+                                                     int klass, const uint32_t *__restrict__ n_dev, const float4 *__restrict__ nodes_sc)
 {
     __shared__ uint32_t stack[BVH_STACK][BS];
     n = queue_fill(n, n_dev);
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(RT_CLOSEST_W
         Best tb = best_none();
         TRay r = tray_make(S, B, o, d);
         float limit = sb.id >= 0 ? sb.t : __builtin_inff();
-        bvh_traverse<MODE, false, BS>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris);
+        bvh_traverse<MODE, false, BS>(B, r, o, d, limit, tb, &stack[0][threadIdx.x], n_nodes, n_tris, nodes_sc);
         hits[j] = merge_hits<MODE>(S, tb, sb);
     }
     bvh_count(counters, klass, n_nodes, n_tris, 0u);

@@ -221,6 +221,31 @@ def test_bounce_rays_one_per_lane_or_refilled(backends, monkeypatch):
             assert got["stats"].rays == ref["stats"].rays == base["stats"].rays
 
 
+@pytest.mark.parametrize("mask", ["0", "1", "2"])
+def test_uniform_steps_through_the_scalar_cache_or_per_lane(mask, backends, monkeypatch):
+    """HIPEXEC_UNIFORM_FETCH: bit 0 lets the shadow rays, bit 1 the bounce and batch closest-hit rays fetch a node record
+    through the scalar cache in the steps in which every lane of the wave sits on the same node (default: both).  Every
+    combination gives the default's frame and hits bit for bit, and the oracle's."""
+    from raytracer_amd.executor import HipExecutor
+    monkeypatch.setenv("HIPEXEC_UNIFORM_FETCH", mask)
+    for name in ("mirror", "soup", "c2"):
+        fs, ex_default, orc = backends(name)
+        with HipExecutor(fs, device=0) as ex:
+            ref = orc.render(61, 83, mode=CPU, max_depth=3, tone=0, n_threads=8)
+            got = ex.render(61, 83, mode=CPU, max_depth=3, tone=False, algo="bvh")
+            base = ex_default.render(61, 83, mode=CPU, max_depth=3, tone=False, algo="bvh")
+            assert np.array_equal(got["ids"], ref["ids"]), name
+            assert np.array_equal(got["rgb"].view(np.int32), base["rgb"].view(np.int32)), name
+            assert got["stats"].rays == ref["stats"].rays == base["stats"].rays
+            rays = _random_rays(fs, 3000, 5)
+            rays[:1500, :3] = rays[0, :3]                    # a bundle from one origin: uniform steps at the top of the tree
+            for mode in (CPU, CL):
+                a, b = ex.closest_hits(rays, mode), ex_default.closest_hits(rays, mode)
+                for k in ("id", "t", "u", "v"):
+                    assert np.array_equal(a[k].view(np.int32), b[k].view(np.int32)), (name, k)
+                assert np.array_equal(a["id"], orc.closest_hits(rays, mode)["id"]), name
+
+
 def test_more_spheres_than_the_shadow_kernel_keeps_in_lds():
     """The shadow-ray kernel keeps the first 64 spheres in LDS and reads the others from memory: 90 spheres, 3 lamps."""
     from raytracer_amd.executor import HipExecutor
