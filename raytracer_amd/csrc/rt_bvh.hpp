@@ -619,8 +619,17 @@ DEV void bvh_burst(const DBvh &B, const TRay &r, f3 o, f3 d, TState &st, Best &b
             // same early read in every inner-node step, or in the leaf step of the packets, whose scalar loads share
             // the wait with it, is slower).
             const uint32_t below = sp > 0 ? stk[BS * (sp - 1)] : BVH_NONE;
+            // (closest-hit rays ask for the second record only where the leaf has one: leaves of a single triangle are common
+            // and that kernel keeps the texture addressers busiest, bounce class -3.4 %; shadow rays ask for both at once
+            // whatever the count: conditional, C5 is 0.6 % slower)
 #pragma unroll
-            for (int i = 0; i < 6; i++) q[i] = T[3 * (size_t)first + i];
+            for (int i = 0; i < 3; i++) q[i] = T[3 * (size_t)first + i];
+#pragma unroll
+            for (int i = 3; i < 6; i++) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ANY || cnt >= 2u) {
+#pragma unroll
+                for (int i = 3; i < 6; i++) q[i] = T[3 * (size_t)first + i];
+            }
             for (uint32_t k = first; k < first + cnt; k++) {
                 if (ANY && found) continue;
                 float4 e0, e1, e2;
