@@ -160,7 +160,7 @@ typedef struct hipexec_render_cfg {
  * colours; they differ in which tests they can prove unnecessary. */
 enum { HIPEXEC_ALGO_SCAN = 0, HIPEXEC_ALGO_BVH = 1 };
 
-#define HIPEXEC_ABI_VERSION 6
+#define HIPEXEC_ABI_VERSION 7
 
 /* Kernel classes reported in hipexec_stats. */
 enum {
@@ -254,6 +254,20 @@ int hipexec_clone(hipexec_t **out, hipexec_t *src);
  * in flight on this executor is waited for first.
  */
 int hipexec_set_camera(hipexec_t *h, const float *cam_pos, const float *cam_mat);
+
+/*
+ * Rebuilds the scene's hierarchy with a better topology; for scenes that are kept for many frames.  No counterpart in
+ * the reference (it has no hierarchy; its executor lives for one frame, ray_tracer_cl.cpp:14, and hipexec_create's
+ * build is made for that: on the device, Morton order, under a millisecond).  This call cuts the triangles top-down by
+ * the surface-area heuristic on the host (8 bins per axis, a few threads; about 10 ms per 100 000 triangles), hands the
+ * binary tree to the same device kernels for boxes and 4-wide records, and waits for them.  Rays then visit 15-20 % fewer
+ * nodes and evaluate 20-30 % fewer exact tests; results do not change by a bit, because the hierarchy only decides which
+ * exact tests are evaluated and the winner rule is explicit (smallest t, then smallest index).  The arrays that all
+ * executors of the scene share (hipexec_clone) are rewritten in place: the call waits for all work on the device first,
+ * and no other executor of the scene may be given work until it returns.  A second call, a scene of at most two
+ * triangles or one without a hierarchy returns at once.  *build_ms (may be NULL): host + device time of the rebuild.
+ */
+int hipexec_optimize(hipexec_t *h, float *build_ms);
 
 /*
  * Returns what the library's pool holds for `device` (-1: every device) to the driver.  No counterpart in the

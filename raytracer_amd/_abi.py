@@ -19,7 +19,7 @@ HIPEXEC_FLAG_REFRACT = 16
 HIPEXEC_FLAG_AO = 32
 HIPEXEC_ALGO_SCAN, HIPEXEC_ALGO_BVH = 0, 1
 K_PRIMARY, K_CLOSEST, K_ANYHIT, K_SHADE, K_COUNT = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATIC_MAX_RAYS = 1 << 18
 
 _fp = C.POINTER(C.c_float)
@@ -105,6 +105,7 @@ PROTOTYPES = {
     "hipexec_destroy": (None, [C.c_void_p]),
     "hipexec_clone": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "hipexec_set_camera": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "hipexec_optimize": (C.c_int, [C.c_void_p, _fp]),
     "hipexec_trim": (C.c_int, [C.c_int]),
     "hipexec_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hipexec_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),

@@ -28,6 +28,7 @@
 #include "hip_executor.h"
 #include "rt_kernels.hpp"
 #include "rt_bvh.hpp"
+#include "rt_bvh_host.hpp"
 #include <hipcub/hipcub.hpp>
 
 using namespace rt;
@@ -336,6 +337,7 @@ struct SceneShare {
     float *d_tri_p = nullptr, *d_tri_e1 = nullptr, *d_tri_e2 = nullptr;   // the caller's triangle arrays on the device (set-up kernels read them)
     std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
     bool scan_shared = false;                 // pair_gen / pair_lamp / chunk_box exist
+    bool optimized = false;                   // the hierarchy has the surface-area topology (hipexec_optimize)
     const PairGen *pair_gen = nullptr; const PairCam *pair_lamp = nullptr; const float4 *chunk_box = nullptr;
     // remembered queue sizes (newest last, at most 64), common to the executors of the scene and their lanes: with
     // several frames in flight each executor sizes its next frame from the newest frame any of them has collected
@@ -509,29 +511,36 @@ int validate_scene(const hipexec_scene_desc *s)
 
 // Hierarchy over the triangles (rt_bvh.hpp).  Scenes with non-finite or astronomically large
 // coordinates, or too many triangles for the leaf encoding, get none and are always scanned.
-int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const double *hi, bool all_finite)
+// `sah` false: the Morton-order radix tree, all on the device (lo / hi: the scene's bounds).  `sah` true: the
+// topology comes from the surface-area build on the host (rt_bvh_host.hpp; waits for the stream, reads the triangle
+// records back) and the arrays of an earlier build are written again in place: nothing may be traversing them.
+int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const double *hi, bool all_finite, bool sah = false)
 {
     const DScene &S = h->S;
     DBvh &B = h->B;
     const uint32_t n = S.n_tri;
-    B.n = n; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
-    B.stack_limit = BVH_STACK;
-    if (const char *e = knob("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
-    B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
-    // clamp of the slab test's reciprocals (tray_make): at least 1e12 * size^2, from the shortest direction that can pass
-    // the exact tests' |det| > 1e-4 with edges of at most 2 sqrt(3) times the scene's size; none where that leaves the float range
-    {
-        const double want = std::max(1.0e30, 1.0e12 * (double)B.scene_mag * (double)B.scene_mag);
-        B.inv_clamp = want < 3.0e38 ? (float)want : std::numeric_limits<float>::infinity();
-    }
-    h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
     float4 *tris = nullptr, *nodes = nullptr; uint32_t *ids = nullptr;
-    CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 3));      // + one record: a one-triangle leaf is fetched as two
-    CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
-    CHK(upload<float4>(h, nullptr, 0, &nodes, BVH_NODE_F4 * (size_t)n + 1));
-    B.tris = tris; B.ids = ids; B.nodes = nodes;
-    if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
-    B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
+    if (!sah) {
+        B.n = n; B.root = BVH_NONE; B.nodes = nullptr; B.tris = nullptr; B.ids = nullptr;
+        B.stack_limit = BVH_STACK;
+        if (const char *e = knob("HIPEXEC_BVH_STACK_LIMIT")) B.stack_limit = std::max(0, std::min(BVH_STACK, atoi(e)));   // test hook
+        B.scene_mag = std::fabs(S.center[0]) + std::fabs(S.center[1]) + std::fabs(S.center[2]) + S.rmax;
+        // clamp of the slab test's reciprocals (tray_make): at least 1e12 * size^2, from the shortest direction that can pass
+        // the exact tests' |det| > 1e-4 with edges of at most 2 sqrt(3) times the scene's size; none where that leaves the float range
+        {
+            const double want = std::max(1.0e30, 1.0e12 * (double)B.scene_mag * (double)B.scene_mag);
+            B.inv_clamp = want < 3.0e38 ? (float)want : std::numeric_limits<float>::infinity();
+        }
+        h->bvh_ok = all_finite && n <= BVH_MAX_TRIS;
+        CHK(upload<float4>(h, nullptr, 0, &tris, 3 * (size_t)n + 3));      // + one record: a one-triangle leaf is fetched as two
+        CHK(upload<uint32_t>(h, nullptr, 0, &ids, (size_t)n + 1));
+        CHK(upload<float4>(h, nullptr, 0, &nodes, BVH_NODE_F4 * (size_t)n + 1));
+        B.tris = tris; B.ids = ids; B.nodes = nodes;
+        if (!h->bvh_ok || n == 0) return HIPEXEC_OK;
+        B.root = (n <= (uint32_t)BVH_LEAF_MAX) ? (BVH_LEAF | (n << 28)) : 0u;
+    } else {
+        tris = const_cast<float4 *>(B.tris); ids = const_cast<uint32_t *>(B.ids); nodes = const_cast<float4 *>(B.nodes);
+    }
 
     // temporaries: one block, carved up, released at the end
     unsigned long long *keys_a = nullptr, *keys_b = nullptr;
@@ -555,20 +564,39 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
         sort_tmp = carve(tmp_bytes);
         HIPCHK(hipMemsetAsync(arrived, 0, 4 * (size_t)n + 4, h->stream));
         uint32_t *top_count = arrived + n;
-        f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
-        float ext[3];
-        for (int k = 0; k < 3; k++) ext[k] = (float)(hi[k] - lo[k]);
-        // cubic Morton cells (one scale for all axes): a flat scene then spends no split on its thin axis
-        float emax = std::max(ext[0], std::max(ext[1], ext[2]));
-        inv.x = inv.y = inv.z = emax > 0.f ? 1.0f / emax : 0.f;
         const dim3 blk(256), grid((n + 255) / 256);
-        hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+        if (!sah) {
+            f3 flo = {(float)lo[0], (float)lo[1], (float)lo[2]}, inv;
+            float ext[3];
+            for (int k = 0; k < 3; k++) ext[k] = (float)(hi[k] - lo[k]);
+            // cubic Morton cells (one scale for all axes): a flat scene then spends no split on its thin axis
+            float emax = std::max(ext[0], std::max(ext[1], ext[2]));
+            inv.x = inv.y = inv.z = emax > 0.f ? 1.0f / emax : 0.f;
+            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+        } else {
+            // (n >= 2 here: hipexec_optimize leaves smaller scenes alone)
+            std::vector<float4> rec(3 * (size_t)n);
+            HIPCHK(hipMemcpyAsync(rec.data(), tri_exact, rec.size() * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HostTopology T;
+            int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+            if (const char *e = knob("HIPEXEC_BUILD_THREADS")) threads = std::max(1, atoi(e));
+            sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T);
+            const uint32_t tc = (uint32_t)T.top_list.size();
+            HIPCHK(hipMemcpyAsync(keys_b, T.keys.data(), 8 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(child, T.child.data(), 4 * T.child.size(), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(parent, T.parent.data(), 4 * T.parent.size(), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(range, T.range.data(), 4 * T.range.size(), hipMemcpyHostToDevice, h->stream));
+            if (tc) HIPCHK(hipMemcpyAsync(top_list, T.top_list.data(), 4 * (size_t)tc, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(top_count, &tc, 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));        // the host arrays end here
+        }
         hipLaunchKernelGGL(k_bvh_leaves, grid, blk, 0, h->stream, n, keys_b, tri_exact, tris, ids, box_lo, box_hi, nrm_lo, nrm_hi);
         HIPCHK(hipGetLastError());
         if (n >= 2) {
-            hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range, top_list, top_count);
+            if (!sah) hipLaunchKernelGGL(k_bvh_split, grid, blk, 0, h->stream, n, keys_b, child, parent, range, top_list, top_count);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_bvh_refit, dim3((n + REFIT_BLOCK - 1) / REFIT_BLOCK), dim3(REFIT_BLOCK), 0, h->stream, n, child, parent, range, arrived,
                                box_lo, box_hi, nrm_lo, nrm_hi);
@@ -1773,6 +1801,33 @@ int hipexec_set_camera(hipexec_t *h, const float *cam_pos, const float *cam_mat)
     // the default algorithm, has nothing that depends on the camera)
     h->scan_ready = false;
     if (!h->bvh_default || !h->bvh_ok) { HIPCHK(hipSetDevice(h->device)); CHK(ensure_scan_records(h)); }
+    return HIPEXEC_OK;
+}
+
+int hipexec_optimize(hipexec_t *h, float *build_ms)
+{
+    if (build_ms) *build_ms = 0.0f;
+    if (!h) return fail(HIPEXEC_E_INVALID, "handle is NULL");
+    if (!h->share) return fail(HIPEXEC_E_INVALID, "a helper lane owns no scene memory");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->call_open) CHK(hipexec_sync(h));
+    if (!h->bvh_ok || h->S.n_tri <= (uint32_t)BVH_LEAF_MAX) return HIPEXEC_OK;      // no hierarchy, or a single leaf
+    std::lock_guard<std::mutex> lk(h->share->m);
+    if (h->share->optimized) return HIPEXEC_OK;
+    // the arrays every executor of the scene traverses are rewritten in place: whatever still runs on the device ends first
+    HIPCHK(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t keep = h->stream;
+    h->stream = h->own_stream;
+    int rc = build_bvh(h, h->S.tri_exact, nullptr, nullptr, true, true);
+    hipError_t e = hipStreamSynchronize(h->own_stream);
+    h->stream = keep;
+    pool_free(h->device, false, h->build_tmp);
+    h->build_tmp = nullptr;
+    CHK(rc);
+    HIPCHK(e);
+    h->share->optimized = true;
+    if (build_ms) *build_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return HIPEXEC_OK;
 }
 

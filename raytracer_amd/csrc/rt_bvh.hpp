@@ -32,7 +32,10 @@ namespace rt {
 
 constexpr uint32_t BVH_LEAF = 0x80000000u;      // reference is a leaf: bits 0..27 first triangle, 28..30 count
 constexpr uint32_t BVH_NONE = 0x7fffffffu;      // no node
-constexpr int BVH_LEAF_MAX = 2;
+#ifndef RT_BVH_LEAF_MAX
+#define RT_BVH_LEAF_MAX 2                       // triangles a leaf holds at most (3 bits in a reference: up to 7)
+#endif
+constexpr int BVH_LEAF_MAX = RT_BVH_LEAF_MAX;
 #ifndef RT_BVH_STACK
 #define RT_BVH_STACK 21
 #endif
