@@ -31,16 +31,21 @@ struct HostTopology {
 
 namespace sah_detail {
 
-constexpr int BINS = 8;                     // 8, 16, 32 and 64 bins measure the same frame times
+constexpr int BINS = 8;                     // 8, 16, 32 and 64 bins measure the same frame times, and so does a full sweep
+                                            // (every position on every axis) for the ranges of up to 64 leaves
 constexpr uint32_t SHARE_ABOVE = 4096;      // a thread hands one half of a range this large to the other threads
 
+// {lo.x, lo.y, lo.z, -, -hi.x, -hi.y, -hi.z, -}: with the upper corner negated a union is one minimum over eight floats,
+// which the compiler turns into two vector instructions (the cuts spend their time growing bin boxes)
 struct Box {
-    float lo[3], hi[3];
-    void reset() { for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } }
-    void grow(const Box &b) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    float v[8];
+    void reset() { for (int k = 0; k < 8; k++) v[k] = 3.0e38f; }
+    void grow(const Box &b) { for (int k = 0; k < 8; k++) v[k] = std::min(v[k], b.v[k]); }
+    float lo(int k) const { return v[k]; }
+    float hi(int k) const { return -v[4 + k]; }
     float area() const {
         float d[3];
-        for (int k = 0; k < 3; k++) d[k] = std::max(0.f, hi[k] - lo[k]);
+        for (int k = 0; k < 3; k++) d[k] = std::max(0.f, hi(k) - lo(k));
         return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
     }
 };
@@ -49,9 +54,9 @@ struct Job { uint32_t a, b, parent; int side; };          // leaves [a, b), b - 
 
 struct Builder {
     uint32_t n, refit_block;
-    std::vector<Box> tb;                    // box of each triangle
-    std::vector<float> cen;                 // [n][3] centre of that box
-    std::vector<uint32_t> idx;              // triangle of the k-th leaf
+    struct Prim { Box box; uint32_t tri; };
+    std::vector<Prim> prim;                 // the k-th leaf's triangle and its box; the cuts reorder the records themselves,
+                                            // so every pass over a range reads consecutive memory
     HostTopology *out;
     uint32_t root_split = 0;                // split position of the root (set by the first job, before any other runs)
     // shared work list of the large ranges
@@ -66,12 +71,25 @@ struct Builder {
 
     // Where to cut the leaves [a, b): the plane between two of BINS bins of the centres' extent, on the axis and at the
     // position where (area of the left boxes) x (count) + (area of the right boxes) x (count) is smallest; the middle
-    // of the range where the centres coincide.  Reorders idx[a, b) and returns the first leaf of the right half.
+    // of the range where the centres coincide.  Reorders prim[a, b) and returns the first leaf of the right half.
     uint32_t split(uint32_t a, uint32_t b) {
+        // Half of all ranges hold two or three leaves, and the bins' fixed cost would dominate the build: two leaves are
+        // cut between them, of three the one goes alone whose leaving gives the smallest cost (the same criterion, exact)
+        if (b - a == 2) return a + 1;
+        if (b - a == 3) {
+            float cost[3];
+            for (int alone = 0; alone < 3; alone++) {
+                Box pair = prim[a + (alone + 1) % 3].box; pair.grow(prim[a + (alone + 2) % 3].box);
+                cost[alone] = prim[a + alone].box.area() + 2.0f * pair.area();
+            }
+            const int alone = cost[0] <= cost[1] ? (cost[0] <= cost[2] ? 0 : 2) : (cost[1] <= cost[2] ? 1 : 2);
+            std::swap(prim[a], prim[a + alone]);
+            return a + 1;
+        }
         float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (uint32_t k = a; k < b; k++) {
-            const float *c = &cen[3 * (size_t)idx[k]];
-            for (int ax = 0; ax < 3; ax++) { clo[ax] = std::min(clo[ax], c[ax]); chi[ax] = std::max(chi[ax], c[ax]); }
+            const Box &t = prim[k].box;
+            for (int ax = 0; ax < 3; ax++) { const float c = centre(t, ax); clo[ax] = std::min(clo[ax], c); chi[ax] = std::max(chi[ax], c); }
         }
         float sc[3]; bool use[3];
         for (int ax = 0; ax < 3; ax++) {
@@ -82,11 +100,11 @@ struct Builder {
         Box bb[3][BINS]; uint32_t bc[3][BINS];
         for (int ax = 0; ax < 3; ax++) for (int i = 0; i < BINS; i++) { bb[ax][i].reset(); bc[ax][i] = 0; }
         for (uint32_t k = a; k < b; k++) {
-            const uint32_t t = idx[k];
+            const Box &t = prim[k].box;
             for (int ax = 0; ax < 3; ax++) {
                 if (!use[ax]) continue;
-                const int i = bin(cen[3 * (size_t)t + ax], clo[ax], sc[ax]);
-                bb[ax][i].grow(tb[t]); bc[ax][i]++;
+                const int i = bin(centre(t, ax), clo[ax], sc[ax]);
+                bb[ax][i].grow(t); bc[ax][i]++;
             }
         }
         int best_ax = -1, best_bin = 0; float best = 3.0e38f;
@@ -107,12 +125,13 @@ struct Builder {
         if (best_ax >= 0) {
             const float lo = clo[best_ax], s = sc[best_ax];
             const int ax = best_ax, cut = best_bin;
-            auto it = std::partition(idx.begin() + a, idx.begin() + b, [&](uint32_t t) { return bin(cen[3 * (size_t)t + ax], lo, s) <= cut; });
-            const uint32_t m2 = (uint32_t)(it - idx.begin());
+            auto it = std::partition(prim.begin() + a, prim.begin() + b, [&](const Prim &t) { return bin(centre(t.box, ax), lo, s) <= cut; });
+            const uint32_t m2 = (uint32_t)(it - prim.begin());
             if (m2 > a && m2 < b) mid = m2;
         }
         return mid;
     }
+    static float centre(const Box &t, int ax) { return 0.5f * t.lo(ax) + 0.5f * t.hi(ax); }
     static int bin(float c, float lo, float s) {
         const float f = (c - lo) * s;
         return f > 0.f ? (f < (float)(BINS - 1) ? (int)f : BINS - 1) : 0;       // NaN -> 0
@@ -185,15 +204,15 @@ inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int
     using namespace sah_detail;
     Builder b;
     b.n = n; b.refit_block = refit_block; b.out = &out;
-    b.tb.resize(n); b.cen.resize(3 * (size_t)n); b.idx.resize(n);
+    b.prim.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const float *r = rec + 12 * (size_t)i;
         for (int k = 0; k < 3; k++) {
             const float v0 = r[k], v1 = r[k] + r[4 + k], v2 = r[k] + r[8 + k];
-            b.tb[i].lo[k] = std::min(v0, std::min(v1, v2)); b.tb[i].hi[k] = std::max(v0, std::max(v1, v2));
-            b.cen[3 * (size_t)i + k] = 0.5f * b.tb[i].lo[k] + 0.5f * b.tb[i].hi[k];
+            b.prim[i].box.v[k] = std::min(v0, std::min(v1, v2)); b.prim[i].box.v[4 + k] = -std::max(v0, std::max(v1, v2));
         }
-        b.idx[i] = i;
+        b.prim[i].box.v[3] = 0.f; b.prim[i].box.v[7] = 0.f;
+        b.prim[i].tri = i;
     }
     out.child.assign(2 * (size_t)(n - 1), 0u); out.range.assign(2 * (size_t)(n - 1), 0u);
     out.parent.assign(2 * (size_t)n - 1, 0xffffffffu); out.top_list.clear();
@@ -209,7 +228,7 @@ inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int
     b.worker();
     for (auto &t : pool) t.join();
     out.keys.resize(n);
-    for (uint32_t k = 0; k < n; k++) out.keys[k] = ((unsigned long long)k << 32) | b.idx[k];
+    for (uint32_t k = 0; k < n; k++) out.keys[k] = ((unsigned long long)k << 32) | b.prim[k].tri;
 }
 
 }  // namespace rt
