@@ -577,13 +577,15 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
         } else {
             // (n >= 2 here: hipexec_optimize leaves smaller scenes alone)
-            std::vector<float4> rec(3 * (size_t)n);
+            std::vector<float4> rec;
+            try { rec.resize(3 * (size_t)n); } catch (const std::exception &) { return fail(HIPEXEC_E_NOMEM, "host memory for the surface-area build"); }
             HIPCHK(hipMemcpyAsync(rec.data(), tri_exact, rec.size() * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             HostTopology T;
             int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
             if (const char *e = knob("HIPEXEC_BUILD_THREADS")) threads = std::max(1, atoi(e));
-            sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T);
+            try { sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T); }
+            catch (const std::exception &e) { return fail(HIPEXEC_E_NOMEM, "surface-area build on the host: %s", e.what()); }     // nothing on the device has been touched yet
             const uint32_t tc = (uint32_t)T.top_list.size();
             HIPCHK(hipMemcpyAsync(keys_b, T.keys.data(), 8 * (size_t)n, hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(child, T.child.data(), 4 * T.child.size(), hipMemcpyHostToDevice, h->stream));

@@ -133,6 +133,12 @@ def test_cli_frame_matches_oracle_and_binding(tmp_path, mode, depth):
     assert np.array_equal(img.view(np.int32), ref["rgb"].view(np.int32))
     got_ids = np.fromfile(ids, np.int32).reshape(ref["ids"].shape)
     assert np.array_equal(got_ids, ref["ids"])
+    # --optimize (hipexec_optimize before the first frame): the same file, bit for bit
+    pfm2 = str(tmp_path / "o2.pfm")
+    r = subprocess.run([CLI, path, "-o", pfm2, "--width", str(W), "--height", str(H), "--mode", mode, "--depth", str(depth),
+                        "--optimize"], capture_output=True, text=True)
+    assert r.returncode == 0 and "surface-area topology" in r.stderr, r.stderr
+    assert open(pfm2, "rb").read() == raw
     png = str(tmp_path / "o.png")
     subprocess.run([CLI, path, "-o", png, "--width", str(W), "--height", str(H), "--mode", mode, "--depth", str(depth)],
                    check=True, capture_output=True)
