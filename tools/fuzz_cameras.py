@@ -1,7 +1,8 @@
 """Randomised parity run on the small variants of the benchmark scenes: random cameras (inside, around and far outside the
 scene, any orientation), random depth, both rule sets, the optional modes where they apply, the hierarchy against the CPU
 oracle (hit ids exact, linear colour within 4 ulp, ray counts equal) and, every fifth camera, the scans against the same
-frame.  python tools/fuzz_cameras.py [first_seed] [cameras per scene]; stops at the first difference and names it."""
+frame.  python tools/fuzz_cameras.py [first_seed] [cameras per scene]; stops at the first difference and names it.
+FUZZ_OPTIMIZE=1: the hierarchy is rebuilt with the surface-area topology first (hipexec_optimize)."""
 import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -33,6 +34,8 @@ for name in ("c1", "c2", "c4", "c5", "mirror", "glass", "ties"):
     p = np.asarray(fs.tri_p, np.float32).reshape(-1, 3)
     lo, hi = p.min(0), p.max(0)
     with HipExecutor(fs, device=0) as ex:
+        if os.environ.get("FUZZ_OPTIMIZE") == "1":
+            ex.optimize()
         for k in range(per_scene):
             rng = np.random.default_rng(first * 1000 + k)
             where = rng.integers(0, 3)
@@ -64,4 +67,4 @@ for name in ("c1", "c2", "c4", "c5", "mirror", "glass", "ties"):
             if k % 100 == 99 and k + 1 < per_scene:
                 print(f"{name}: {k + 1} cameras so far ({time.time() - t0:.0f} s)", flush=True)
     print(f"{name}: {per_scene} cameras agree ({frames} frames, {time.time() - t0:.0f} s)", flush=True)
-print(f"{frames} frames of 7 scenes from seed {first}: ids exact, colour within 4 ulp, ray counts equal")
+print(f"{frames} frames of 7 scenes from seed {first}{' (surface-area topology)' if os.environ.get('FUZZ_OPTIMIZE') == '1' else ''}: ids exact, colour within 4 ulp, ray counts equal")

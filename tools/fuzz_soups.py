@@ -1,7 +1,7 @@
 """Randomised parity run: triangle soups of random size and scale (tests/test_gpu_cull.py's generator and adversarial rays,
 other seeds), the hierarchy against the index-order scans bit for bit (closest hits, any hits, a depth-3 frame, both rule
 sets) and both against the CPU oracle.  python tools/fuzz_soups.py [first_seed] [count]; stops at the first difference
-and names its seed."""
+and names its seed.  FUZZ_OPTIMIZE=1: the hierarchy is rebuilt with the surface-area topology first (hipexec_optimize)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,6 +24,8 @@ for seed in range(first, first + count):
     W, H, depth = 56, 40, int(rng.integers(0, 4))
     orc = Oracle(fs)
     with HipExecutor(fs, device=0) as ex:
+        if os.environ.get("FUZZ_OPTIMIZE") == "1":
+            ex.optimize()
         res = {}
         for algo in ("bvh", "scan"):
             ex.set_algorithm(algo)
@@ -53,5 +55,5 @@ for seed in range(first, first + count):
     n_rays += 2 * len(rays); n_px += W * H
     if (seed - first) % 10 == 9:
         print(f"seeds {first}..{seed} agree ({n_rays} batch rays, {n_px} pixels, {time.time() - t0:.0f} s)", flush=True)
-print(f"{count} soups from seed {first}: hierarchy == scan bit for bit, both == oracle ({n_rays} batch rays x 2 rule sets x closest + any hit, "
+print(f"{count} soups from seed {first}{' (surface-area topology)' if os.environ.get('FUZZ_OPTIMIZE') == '1' else ''}: hierarchy == scan bit for bit, both == oracle ({n_rays} batch rays x 2 rule sets x closest + any hit, "
       f"{n_px} pixels of depth 0-3 frames)")
