@@ -80,6 +80,12 @@ def test_c2_full_size_depth3():
         s = ex.render(W, H, max_depth=depth, algo="scan")     # index-order scans: same frame bit for bit
         assert np.array_equal(s["rgb"].view(np.int32), a["rgb"].view(np.int32)) and np.array_equal(s["ids"], a["ids"])
         assert rays == a["stats"].rays == s["stats"].rays and tri_any == s["stats"].tests_tri_any > 0
+        # the hierarchy rebuilt with the surface-area topology (hipexec_optimize): the same frame bit for bit, fewer node visits
+        assert ex.optimize() > 0.0
+        o = ex.render(W, H, max_depth=depth)
+        assert np.array_equal(o["rgb"].view(np.int32), a["rgb"].view(np.int32)) and np.array_equal(o["ids"], a["ids"])
+        assert o["stats"].rays == a["stats"].rays and o["stats"].bvh_stack_overflows == 0
+        assert sum(o["stats"].bvh_nodes) < 0.9 * sum(a["stats"].bvh_nodes)
     ids = a["ids"]
     assert ids.min() >= -1 and ids.max() < fs.n_tri + fs.n_sph
     assert (ids >= fs.n_tri).any() and (ids == -1).any() and ((ids >= 0) & (ids < fs.n_tri)).any()
@@ -105,6 +111,14 @@ def test_c3_4k_depth5_shards_of_eight():
             rays += p["stats"].rays
         assert np.array_equal(img.view(np.int32), a["rgb"].view(np.int32)), "tile shards do not compose"
         assert rays == a["stats"].rays and a["stats"].bvh_stack_overflows == 0
+        ex.optimize()                                         # surface-area topology: the same 4K depth-5 frame, whole and as a shard
+        o = ex.render(W, H, max_depth=depth)
+        assert np.array_equal(o["rgb"].view(np.int32), a["rgb"].view(np.int32)) and np.array_equal(o["ids"], a["ids"])
+        assert o["stats"].rays == a["stats"].rays and o["stats"].bvh_stack_overflows == 0
+        img2 = np.full((H, W, 3), -1, np.float32)
+        ex.render(W, H, max_depth=depth, tile_first=3, tile_step=8, out=img2, want_ids=False)
+        rows = np.arange(H)[(np.arange(H) // 8) % 8 == 3]
+        assert np.array_equal(img2[rows].view(np.int32), a["rgb"][rows].view(np.int32))
     orc = Oracle(fs)
     for (x, y) in _blocks(W, H, 3, 2):
         ref = orc.render_region(W, H, x, y, 8, 8, mode=_abi.HIPEXEC_MODE_CPU, max_depth=depth, tone=1, n_threads=8)
@@ -180,6 +194,11 @@ def test_c5_whole_4k_frame_in_one_call():
             p = ex.render(W, H, max_depth=0, tile_first=r, tile_step=2, out=img, want_ids=False)
             rays += p["stats"].rays
         assert np.array_equal(img.view(np.int32), a["rgb"].view(np.int32)), "tile shards do not compose"
+        ex.optimize()                                         # surface-area topology: the same frame bit for bit
+        o = ex.render(W, H, max_depth=0)
+        assert np.array_equal(o["rgb"].view(np.int32), a["rgb"].view(np.int32)) and np.array_equal(o["ids"], a["ids"])
+        assert o["stats"].rays == a["stats"].rays and o["stats"].bvh_stack_overflows == 0
+        assert sum(o["stats"].bvh_nodes) < 0.9 * sum(a["stats"].bvh_nodes)
     st = a["stats"]
     assert st.rays_primary == W * H * 4 and st.rays_shadow > st.rays_primary and st.rays == rays
     assert st.bvh_stack_overflows == 0
