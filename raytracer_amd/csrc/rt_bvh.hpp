@@ -9,7 +9,7 @@
 // only if no exact test in it can succeed.
 //
 // Build (all on the device, once per scene):
-//   k_bvh_keys    30-bit Morton code of each centroid, key = code << 32 | triangle index
+//   k_bvh_keys    30-bit Morton code of the centre of each triangle's box, key = code << 32 | triangle index
 //   radix sort    hipcub::DeviceRadixSort on the 64-bit keys (unique by construction)
 //   k_bvh_leaves  triangle records gathered into key order, leaf boxes
 //   k_bvh_split   binary radix tree over the sorted keys, one thread per internal node
@@ -98,7 +98,13 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 p = xyz(tri_exact[3 * (size_t)i]), e1 = xyz(tri_exact[3 * (size_t)i + 1]), e2 = xyz(tri_exact[3 * (size_t)i + 2]);
-    f3 c = p + (e1 + e2) * (1.0f / 3.0f);
+    // Centre of the triangle's BOX, not of its vertices: the two triangles a quad was cut into share it, get the same code, sort
+    // next to each other and become one two-triangle leaf with the quad's box (by their vertex centroids they straddle grid
+    // planes, and a leaf then pairs halves of neighbouring quads).  Node visits per ray -10 %, exact tests -25 %; frames with
+    // this build: C2 2.73 -> 2.37 ms, C4 1.04 -> 0.92 ms, C5 16.5 -> 14.6 ms, C1 0.239 -> 0.218 ms.
+    f3 a = p + e1, b = p + e2;
+    f3 c = mk(0.5f * (fminf(p.x, fminf(a.x, b.x)) + fmaxf(p.x, fmaxf(a.x, b.x))), 0.5f * (fminf(p.y, fminf(a.y, b.y)) + fmaxf(p.y, fmaxf(a.y, b.y))),
+              0.5f * (fminf(p.z, fminf(a.z, b.z)) + fmaxf(p.z, fmaxf(a.z, b.z))));
     float q[3] = {(c.x - lo.x) * inv_ext.x, (c.y - lo.y) * inv_ext.y, (c.z - lo.z) * inv_ext.z};
     uint32_t g[3];
     for (int k = 0; k < 3; k++) {
