@@ -572,6 +572,12 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             // cubic Morton cells (one scale for all axes): a flat scene then spends no split on its thin axis
             float emax = std::max(ext[0], std::max(ext[1], ext[2]));
             inv.x = inv.y = inv.z = emax > 0.f ? 1.0f / emax : 0.f;
+            if (const char *e = knob("HIPEXEC_MORTON_FLAT")) {            // experiment: an axis thinner than emax * value gets no code bits
+                const float f = (float)atof(e);
+                if (ext[0] < f * emax) inv.x = 0.f;
+                if (ext[1] < f * emax) inv.y = 0.f;
+                if (ext[2] < f * emax) inv.z = 0.f;
+            }
             hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
@@ -684,6 +690,10 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
             }
         }
     }
+    // bounds of the triangles alone: the grid of the hierarchy's Morton codes (a camera or a sphere far from the mesh would
+    // otherwise spend the codes' leading bits on empty space)
+    double tri_lo[3], tri_hi[3];
+    for (int k = 0; k < 3; k++) { tri_lo[k] = lo[k]; tri_hi[k] = hi[k]; }
     for (uint32_t i = 0; i < s->n_sph; i++) grow(s->sph_center[3 * i], s->sph_center[3 * i + 1], s->sph_center[3 * i + 2]);
     grow(s->cam_pos[0], s->cam_pos[1], s->cam_pos[2]);
     for (int k = 0; k < 3; k++) S.center[k] = (lo[k] <= hi[k]) ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
@@ -723,7 +733,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
     }
     STAGE("triangle upload + exact");
-    CHK(build_bvh(h, ex, lo, hi, all_finite));
+    CHK(build_bvh(h, ex, tri_lo, tri_hi, all_finite));
     STAGE("hierarchy build");
     // what the build does not read goes up on the side stream while the build's kernels run
     h->upload_stream = h->side;
