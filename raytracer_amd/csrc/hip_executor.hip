@@ -362,6 +362,7 @@ struct hipexec {
     uint32_t lamp_words = 1;
     hipStream_t upload_stream = nullptr;      // stream of upload() while it is not the executor's (scene set-up: beside the hierarchy build)
     void *build_tmp = nullptr;                // temporaries of the hierarchy build, until the build has been waited for
+    int morton_minor = -1;                    // axis whose code bits come last in the device build (-1: none), see build_scene
     bool scan_ready = false;                  // the scan algorithm's records exist and belong to this executor's camera (ensure_scan_records)
     Buf cam_primx, cam_pairs;                 // the camera-dependent scan records of this executor (k_setup_cam_pairs)
     Buf rayA, rayB, hit0, hitN, hitM, local, occl, shadowq, out_rgba, out_ids, stage_in, stage_out;
@@ -572,13 +573,13 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             // cubic Morton cells (one scale for all axes): a flat scene then spends no split on its thin axis
             float emax = std::max(ext[0], std::max(ext[1], ext[2]));
             inv.x = inv.y = inv.z = emax > 0.f ? 1.0f / emax : 0.f;
-            if (const char *e = knob("HIPEXEC_MORTON_FLAT")) {            // experiment: an axis thinner than emax * value gets no code bits
-                const float f = (float)atof(e);
-                if (ext[0] < f * emax) inv.x = 0.f;
-                if (ext[1] < f * emax) inv.y = 0.f;
-                if (ext[2] < f * emax) inv.z = 0.f;
-            }
-            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, keys_a);
+            // A thin axis the surfaces lie across (a terrain's height) gets the LAST ten bits of the code instead of every
+            // third one: a cut on it divides a patch of surface along a contour line where a cut on the other two axes
+            // halves it, so the other two are spent first and the thin one only separates what shares their cell
+            // (walls, stacked geometry).  HIPEXEC_MORTON_MINOR=-1 keeps the plain interleave, 0..2 names the axis.
+            int minor = h->morton_minor;
+            if (const char *e = knob("HIPEXEC_MORTON_MINOR")) minor = std::max(-1, std::min(2, atoi(e)));
+            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, keys_a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
         } else {
@@ -733,6 +734,24 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         S.cull = (nc && nc[0] == '1') ? 0u : 1u;
     }
     STAGE("triangle upload + exact");
+    // Axis for the last bits of the hierarchy's Morton codes: the thinnest one that is under a quarter of the largest extent
+    // and that the triangles' normals mostly point along (mean |n_k| > 0.8: surfaces lie across it, as a terrain's height)
+    h->morton_minor = -1;
+    if (all_finite && s->n_tri) {
+        double sum[3] = {0.0, 0.0, 0.0};
+        size_t cnt = 0;
+        const size_t stride = std::max<size_t>(1, s->n_tri / 65536);           // a sample is enough for a mean
+        for (size_t i = 0; i < s->n_tri; i += stride) {
+            const float *nn = s->tri_norm + 3 * i;
+            if (!(std::fabs(nn[0]) <= 1.5f) || !(std::fabs(nn[1]) <= 1.5f) || !(std::fabs(nn[2]) <= 1.5f)) continue;      // NaN of a zero-area triangle
+            for (int k = 0; k < 3; k++) sum[k] += std::fabs(nn[k]);
+            cnt++;
+        }
+        double ext[3], emax = 0.0;
+        for (int k = 0; k < 3; k++) { ext[k] = tri_hi[k] - tri_lo[k]; emax = std::max(emax, ext[k]); }
+        for (int k = 0; k < 3; k++)
+            if (cnt && ext[k] < 0.25 * emax && sum[k] > 0.8 * (double)cnt && (h->morton_minor < 0 || ext[k] < ext[h->morton_minor])) h->morton_minor = k;
+    }
     CHK(build_bvh(h, ex, tri_lo, tri_hi, all_finite));
     STAGE("hierarchy build");
     // what the build does not read goes up on the side stream while the build's kernels run

@@ -92,7 +92,17 @@ DEV uint32_t morton_spread(uint32_t v) {        // 10 bits -> every third bit
     return v;
 }
 
-__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext,
+DEV uint32_t morton_spread2(uint32_t v) {       // 10 bits -> every second bit
+    v &= 0x3ffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+// `minor` = -1: the three axes interleaved; 0..2: that axis' ten bits come last, the other two are interleaved above them
+__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext, int minor,
                            unsigned long long *__restrict__ keys)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,6 +122,10 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
         g[k] = (f > 0.f) ? (f < 1023.0f ? (uint32_t)f : 1023u) : 0u;        // NaN -> 0
     }
     uint32_t code = morton_spread(g[0]) | (morton_spread(g[1]) << 1) | (morton_spread(g[2]) << 2);
+    if (minor >= 0) {
+        const uint32_t ga = g[minor == 0 ? 1 : 0], gb = g[minor == 2 ? 1 : 2];
+        code = ((morton_spread2(ga) | (morton_spread2(gb) << 1)) << 10) | g[minor];
+    }
     keys[i] = ((unsigned long long)code << 32) | i;
 }
 
