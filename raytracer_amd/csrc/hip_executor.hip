@@ -577,9 +577,12 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             // third one: a cut on it divides a patch of surface along a contour line where a cut on the other two axes
             // halves it, so the other two are spent first and the thin one only separates what shares their cell
             // (walls, stacked geometry).  HIPEXEC_MORTON_MINOR=-1 keeps the plain interleave, 0..2 names the axis.
+            // (HIPEXEC_CLASS_BITS=0: no orientation classes in the codes, see k_bvh_keys; hipexec_optimize always parts them)
+            const char *cb = knob("HIPEXEC_CLASS_BITS");
+            const int classes = (cb && cb[0] == '0') ? 0 : 1;
             int minor = h->morton_minor;
             if (const char *e = knob("HIPEXEC_MORTON_MINOR")) minor = std::max(-1, std::min(2, atoi(e)));
-            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, keys_a);
+            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, classes, keys_a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
         } else {

@@ -101,8 +101,9 @@ DEV uint32_t morton_spread2(uint32_t v) {       // 10 bits -> every second bit
     return v;
 }
 
-// `minor` = -1: the three axes interleaved; 0..2: that axis' ten bits come last, the other two are interleaved above them
-__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext, int minor,
+// `minor` = -1: the three axes interleaved; 0..2: that axis' ten bits come last, the other two are interleaved above them;
+// `classes`: the two leading bits name the orientation class (the code loses its two last bits)
+__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext, int minor, int classes,
                            unsigned long long *__restrict__ keys)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,6 +126,16 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
     if (minor >= 0) {
         const uint32_t ga = g[minor == 0 ? 1 : 0], gb = g[minor == 2 ? 1 : 2];
         code = ((morton_spread2(ga) | (morton_spread2(gb) << 1)) << 10) | g[minor];
+    }
+    if (classes) {
+        // The axis the triangle's normal is closest to leads the code, so the three orientation classes become subtrees under
+        // the root.  A node's normal cone decides whether a ray may use the tight enlargement of its boxes (see TRay); in a
+        // subtree that mixes walls, floors and roofs no cone exists, every box takes the loose enlargement (proportional to
+        // the distance), and nothing is culled: a scene of 1500 boxes on a ground grid took 288 ms per 720p frame, 11.7 ms
+        // with the classes apart; C1 (a box on a plane) 0.212 -> 0.110 ms; the terrains, one class, are unchanged.
+        const float nx = fabsf(tri_exact[3 * (size_t)i].w), ny = fabsf(tri_exact[3 * (size_t)i + 1].w), nz = fabsf(tri_exact[3 * (size_t)i + 2].w);
+        const uint32_t cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
+        code = (code >> 2) | (cls << 28);
     }
     keys[i] = ((unsigned long long)code << 32) | i;
 }

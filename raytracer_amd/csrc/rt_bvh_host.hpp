@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -54,7 +55,7 @@ struct Job { uint32_t a, b, parent; int side; };          // leaves [a, b), b - 
 
 struct Builder {
     uint32_t n, refit_block;
-    struct Prim { Box box; uint32_t tri; };
+    struct Prim { Box box; uint32_t tri, cls; };         // cls: the axis the triangle's normal is closest to (0..2)
     std::vector<Prim> prim;                 // the k-th leaf's triangle and its box; the cuts reorder the records themselves,
                                             // so every pass over a range reads consecutive memory
     HostTopology *out;
@@ -76,6 +77,16 @@ struct Builder {
         // Half of all ranges hold two or three leaves, and the bins' fixed cost would dominate the build: two leaves are
         // cut between them, of three the one goes alone whose leaving gives the smallest cost (the same criterion, exact)
         if (b - a == 2) return a + 1;
+        // Orientation classes are parted first (they end up as subtrees under the root): a node's normal cone, which
+        // decides whether a ray may use the tight enlargement of the boxes, is only as narrow as the normals below it
+        {
+            uint32_t cmin = 3, cmax = 0;
+            for (uint32_t k = a; k < b; k++) { cmin = std::min(cmin, prim[k].cls); cmax = std::max(cmax, prim[k].cls); }
+            if (cmin != cmax) {
+                auto it = std::partition(prim.begin() + a, prim.begin() + b, [&](const Prim &t) { return t.cls == cmin; });
+                return (uint32_t)(it - prim.begin());
+            }
+        }
         if (b - a == 3) {
             float cost[3];
             for (int alone = 0; alone < 3; alone++) {
@@ -197,7 +208,8 @@ struct Builder {
 
 }  // namespace sah_detail
 
-// `rec`: 12 floats per triangle, {p.xyz, -}{e1.xyz, -}{e2.xyz, -} (the device's exact-test records); n >= 2.
+// `rec`: 12 floats per triangle, {p.xyz, c.x}{e1.xyz, c.y}{e2.xyz, c.z} with c = cross(e2, e1) (the device's exact-test
+// records); n >= 2.
 // Coordinates are finite (a scene with others gets no hierarchy at all).
 inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int threads, HostTopology &out)
 {
@@ -213,6 +225,8 @@ inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int
         }
         b.prim[i].box.v[3] = 0.f; b.prim[i].box.v[7] = 0.f;
         b.prim[i].tri = i;
+        const float nx = std::fabs(r[3]), ny = std::fabs(r[7]), nz = std::fabs(r[11]);        // cross(e2, e1), as the device's keys read it
+        b.prim[i].cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
     }
     out.child.assign(2 * (size_t)(n - 1), 0u); out.range.assign(2 * (size_t)(n - 1), 0u);
     out.parent.assign(2 * (size_t)n - 1, 0xffffffffu); out.top_list.clear();

@@ -346,6 +346,25 @@ def scene_soup(seed=9, n_tri=1500, extent=10.0) -> SceneSpec:
                      {"ambientColor": [0.05, 0.05, 0.05], "horizonColor": [0.2, 0.3, 0.4], "ambientFactor": 0.0})
 
 
+def scene_city(seed=12, cells=96, n_boxes=1500) -> SceneSpec:
+    """Not a benchmark config: a ground grid with boxes of random size standing on it (walls, roofs and ground mix their
+    orientations in every neighbourhood, as a modelled scene does and the terrains of configs 2-5 do not), 2 lamps."""
+    rng = np.random.default_rng(seed)
+    gv, gf, _ = grid_mesh(cells, cells, -24, 24, -40, 8)
+    mats = [material((0.6, 0.6, 0.55), kd=0.8, ks=0.2, hard=20, kr=0.1), material((0.7, 0.5, 0.3), kd=0.9, ks=0.4, hard=40)]
+    meshes = [(gv, gf, None, 0)]
+    for _ in range(n_boxes):
+        x, z = rng.uniform(-23, 22), rng.uniform(-39, 7)
+        w, d, hgt = rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.3, 3.0)
+        bv, bf = box_mesh((x, 0, z), (x + w, hgt, z + d))
+        meshes.append((bv, bf, None, 1))
+    V, F, UV, HAS, M = _merge(meshes)
+    T, pos = camera((0, 9, 16), pitch_deg=-22)
+    lamps = [{"pos": [10, 14, 6], "intensity": 1.0, "distance": 45.0}, {"pos": [-14, 10, -20], "intensity": 0.8, "distance": 45.0}]
+    return SceneSpec(V, F, None, None, M, mats, [], lamps, T, pos,
+                     {"ambientColor": [0.05, 0.05, 0.06], "horizonColor": [0.45, 0.5, 0.6], "ambientFactor": 0.0})
+
+
 def small_variant(name: str) -> SceneSpec:
     """Reduced-size versions of the benchmark scenes for parity tests."""
     return {
@@ -358,7 +377,8 @@ def small_variant(name: str) -> SceneSpec:
         "glass": scene_glass,
         "ties": scene_ties,
         "soup": scene_soup,
+        "city": lambda: scene_city(cells=16, n_boxes=40),
     }[name]()
 
 
-SMALL_SCENES = ("c1", "c1_frac", "c2", "c4", "c5", "mirror", "ties")
+SMALL_SCENES = ("c1", "c1_frac", "c2", "c4", "c5", "mirror", "ties", "city")

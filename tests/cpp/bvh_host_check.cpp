@@ -5,9 +5,11 @@
 //   * an inner node's range is the concatenation of its children's ranges (left first)
 //   * top_list holds exactly the inner nodes whose range crosses a block boundary
 //   * the tree does not depend on the number of threads
+//   * triangles of one orientation class (axis closest to the normal) are contiguous in the leaf order
 // usage: bvh_host_check [n_for_timing]   -> prints "ok" and, with an argument, the build time of a grid of that size
 #include "rt_bvh_host.hpp"
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -16,9 +18,32 @@
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { if (fails++ < 10) fprintf(stderr, "FAILED %s (line %d)\n", #c, __LINE__); } } while (0)
 
-static void check(uint32_t n, const std::vector<float> &rec, uint32_t block, int threads, rt::HostTopology &T)
+// fills the w words with cross(e2, e1), as the device's records have them
+static std::vector<float> with_normals(uint32_t n, std::vector<float> r)
 {
+    for (uint32_t i = 0; i < n; i++) {
+        float *t = &r[12 * (size_t)i];
+        const float *e1 = t + 4, *e2 = t + 8;
+        t[3] = e2[1] * e1[2] - e2[2] * e1[1]; t[7] = e2[2] * e1[0] - e2[0] * e1[2]; t[11] = e2[0] * e1[1] - e2[1] * e1[0];
+    }
+    return r;
+}
+
+static void check(uint32_t n, const std::vector<float> &rec_in, uint32_t block, int threads, rt::HostTopology &T)
+{
+    const std::vector<float> rec = with_normals(n, rec_in);
     rt::sah_topology(n, rec.data(), block, threads, T);
+    // orientation classes are parted before anything else: along the leaf order the class changes at most twice
+    {
+        int changes = 0; uint32_t last = 9;
+        for (uint32_t k = 0; k < n; k++) {
+            const float *t = &rec[12 * (size_t)(T.keys[k] & 0xffffffffu)];
+            const float nx = std::fabs(t[3]), ny = std::fabs(t[7]), nz = std::fabs(t[11]);
+            const uint32_t cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
+            if (cls != last) { changes += last != 9; last = cls; }
+        }
+        CHECK(changes <= 2);
+    }
     CHECK(T.keys.size() == n && T.child.size() == 2 * (size_t)(n - 1) && T.range.size() == 2 * (size_t)(n - 1) && T.parent.size() == 2 * (size_t)n - 1);
     std::vector<char> seen(n, 0);
     for (uint32_t k = 0; k < n; k++) {

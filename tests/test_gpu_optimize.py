@@ -26,7 +26,7 @@ def _answers(ex, rays, w, h, depth):
     return out, fr
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5", "soup", "ties", "glass"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5", "soup", "ties", "glass", "city"])
 def test_optimized_hierarchy_gives_the_same_bits_and_the_oracles(name):
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
@@ -113,3 +113,38 @@ def test_random_soups_optimized_equals_scan(seed, n_tri, extent):
             res[algo] = per
         for k, (a, b) in enumerate(zip(res["bvh"], res["scan"])):
             assert np.array_equal(a, b), f"result {k}: {np.count_nonzero(a != b)} entries differ"
+
+
+def test_orientation_classes_keep_mixed_scenes_culled():
+    """Boxes on a ground grid: walls, roofs and ground in every neighbourhood.  A subtree that mixes them has no normal cone,
+    its boxes take the loose enlargement and nothing is culled (without the classes: 1000 and more node visits per ray,
+    millions of stack overflows), so both builds part the orientation classes under the root.  The frame must be the
+    oracle's on a grid of blocks, identical for both builds and for the build without classes, with few node visits and no
+    stack overflow."""
+    import os
+    from raytracer_amd.executor import HipExecutor
+    from oracle.binding import Oracle
+    fs = scenegen.scene_city(cells=48, n_boxes=400).to_flat()
+    W, H, depth = 320, 200, 2
+    with HipExecutor(fs, device=0) as ex:
+        a = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
+        ex.optimize()
+        b = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
+    os.environ["HIPEXEC_CLASS_BITS"] = "0"
+    try:
+        with HipExecutor(fs, device=0) as ex:
+            c = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
+    finally:
+        os.environ.pop("HIPEXEC_CLASS_BITS", None)
+    for f in (b, c):
+        assert np.array_equal(f["ids"], a["ids"]) and np.array_equal(f["rgb"].view(np.int32), a["rgb"].view(np.int32))
+    for f in (a, b):
+        st = f["stats"]
+        assert st.bvh_stack_overflows == 0
+        assert sum(st.bvh_nodes) < 150 * st.rays, "the hierarchy does not cull"
+    assert sum(c["stats"].bvh_nodes) > 3 * sum(a["stats"].bvh_nodes)
+    orc = Oracle(fs)
+    for (x, y) in ((0, 0), (152, 96), (312, 192), (96, 40), (224, 152)):
+        ref = orc.render_region(W, H, x, y, 8, 8, mode=CPU, max_depth=depth, tone=0, n_threads=1)
+        assert np.array_equal(a["ids"][y:y + 8, x:x + 8], ref["ids"]), f"hit ids differ in block {(x, y)}"
+        assert ulp_diff(a["rgb"][y:y + 8, x:x + 8], ref["linear"]).max() <= 4
