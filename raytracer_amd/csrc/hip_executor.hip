@@ -549,7 +549,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
     float4 *box_lo = nullptr, *box_hi = nullptr, *nrm_lo = nullptr, *nrm_hi = nullptr;
     void *sort_tmp = nullptr;
     size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+    HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_a, keys_b, (int)n, 0, 63, h->stream));
     char *block = nullptr;
     size_t used = 0;
     auto carve = [&](size_t bytes) -> void * { void *p = block + used; used += (bytes + 255) / 256 * 256; return p; };
@@ -577,14 +577,18 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             // third one: a cut on it divides a patch of surface along a contour line where a cut on the other two axes
             // halves it, so the other two are spent first and the thin one only separates what shares their cell
             // (walls, stacked geometry).  HIPEXEC_MORTON_MINOR=-1 keeps the plain interleave, 0..2 names the axis.
-            // (HIPEXEC_CLASS_BITS=0: no orientation classes in the codes, see k_bvh_keys; hipexec_optimize always parts them)
+            // (HIPEXEC_CLASS_BITS, for both builds: 0 no orientation classes, 1 the three axis classes, 2 normal cells for large
+            // triangles: the default, see k_bvh_keys)
             const char *cb = knob("HIPEXEC_CLASS_BITS");
-            const int classes = (cb && cb[0] == '0') ? 0 : 1;
+            const int classes = cb ? std::max(0, std::min(2, atoi(cb))) : 2;
+            // a triangle counts as large from sqrt(|e1||e2|) = 16 / (scene size) on: from there its loose enlargement, 3e-2 |e1||e2|
+            // times the distance, exceeds its own size at scene-size distances
+            const float big_thr = emax > 0.f ? 256.0f / (emax * emax) : 3.0e38f;
             int minor = h->morton_minor;
             if (const char *e = knob("HIPEXEC_MORTON_MINOR")) minor = std::max(-1, std::min(2, atoi(e)));
-            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, classes, keys_a);
+            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, classes, big_thr, keys_a);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 62, h->stream));
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 63, h->stream));
         } else {
             // (n >= 2 here: hipexec_optimize leaves smaller scenes alone)
             std::vector<float4> rec;
@@ -594,7 +598,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             HostTopology T;
             int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
             if (const char *e = knob("HIPEXEC_BUILD_THREADS")) threads = std::max(1, atoi(e));
-            try { sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T); }
+            try { sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T, knob("HIPEXEC_CLASS_BITS") ? std::max(0, std::min(2, atoi(knob("HIPEXEC_CLASS_BITS")))) : 2); }
             catch (const std::exception &e) { return fail(HIPEXEC_E_NOMEM, "surface-area build on the host: %s", e.what()); }     // nothing on the device has been touched yet
             const uint32_t tc = (uint32_t)T.top_list.size();
             HIPCHK(hipMemcpyAsync(keys_b, T.keys.data(), 8 * (size_t)n, hipMemcpyHostToDevice, h->stream));

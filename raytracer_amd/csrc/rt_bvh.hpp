@@ -102,8 +102,26 @@ DEV uint32_t morton_spread2(uint32_t v) {       // 10 bits -> every second bit
 }
 
 // `minor` = -1: the three axes interleaved; 0..2: that axis' ten bits come last, the other two are interleaved above them;
-// `classes`: the two leading bits name the orientation class (the code loses its two last bits)
-__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext, int minor, int classes,
+// `classes`: leading bits name the orientation class (the code loses as many of its last bits), see below
+// Orientation class of a triangle for the leading code bits: 0 for a triangle too small for the loose enlargement of the
+// boxes to matter (|e1||e2| <= big_thr), else 1 + the cell of its unit normal (one hemisphere, as the cones take it) in a
+// 15 x 15 octahedral map, the cell's two indices bit-interleaved so that neighbouring directions share leading bits; the axis
+// directions fall in the middle of cells.  (rt_bvh_host.hpp has the same function for the host build.)
+DEV uint32_t bvh_normal_class(f3 c, f3 e1, f3 e2, float big_thr) {
+    const float ee = sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2));
+    if (!(ee > big_thr)) return 0u;
+    if (c.x * 0.267f + c.y * 0.535f + c.z * 0.802f < 0.f) c = -c;
+    const float l1 = fabsf(c.x) + fabsf(c.y) + fabsf(c.z);
+    if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0u;
+    float u = c.x / l1, v = c.y / l1;
+    if (c.z < 0.f) { const float uu = (1.0f - fabsf(v)) * (u < 0.f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.f ? -1.0f : 1.0f); u = uu; v = vv; }
+    const uint32_t qu = (uint32_t)fminf(14.0f, fmaxf(0.0f, (u + 1.0f) * 7.0f + 0.5f)), qv = (uint32_t)fminf(14.0f, fmaxf(0.0f, (v + 1.0f) * 7.0f + 0.5f));
+    uint32_t bin = 0;
+    for (int b = 0; b < 4; b++) bin |= (((qu >> b) & 1u) << (2 * b)) | (((qv >> b) & 1u) << (2 * b + 1));
+    return 1u + bin;
+}
+
+__global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext, int minor, int classes, float big_thr,
                            unsigned long long *__restrict__ keys)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,19 +141,25 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
         g[k] = (f > 0.f) ? (f < 1023.0f ? (uint32_t)f : 1023u) : 0u;        // NaN -> 0
     }
     uint32_t code = morton_spread(g[0]) | (morton_spread(g[1]) << 1) | (morton_spread(g[2]) << 2);
+    const uint32_t code3 = code;
     if (minor >= 0) {
         const uint32_t ga = g[minor == 0 ? 1 : 0], gb = g[minor == 2 ? 1 : 2];
         code = ((morton_spread2(ga) | (morton_spread2(gb) << 1)) << 10) | g[minor];
     }
-    if (classes) {
-        // The axis the triangle's normal is closest to leads the code, so the three orientation classes become subtrees under
-        // the root.  A node's normal cone decides whether a ray may use the tight enlargement of its boxes (see TRay); in a
-        // subtree that mixes walls, floors and roofs no cone exists, every box takes the loose enlargement (proportional to
-        // the distance), and nothing is culled: a scene of 1500 boxes on a ground grid took 288 ms per 720p frame, 11.7 ms
-        // with the classes apart; C1 (a box on a plane) 0.212 -> 0.110 ms; the terrains, one class, are unchanged.
+    // Orientation classes lead the code, so that they become subtrees under the root.  A node's normal cone decides whether a
+    // ray may use the tight enlargement of its boxes (see TRay); in a subtree that mixes walls, floors and roofs no cone exists,
+    // every box takes the loose enlargement (proportional to |e1||e2| and the distance), and nothing is culled: a scene of
+    // 1500 boxes on a ground grid took 288 ms per 720p frame, 11.7 ms with the classes apart; C1 (a box on a plane) 0.212 ->
+    // 0.110 ms; the terrains, whose triangles are small, are unchanged.  classes == 1: the axis the normal is closest to
+    // (two bits); classes == 2, the default: for large triangles the cell of the normal in an octahedral map (walls that
+    // stand at any angle: 150 -> 68 ms for the same boxes turned by random angles), small triangles stay together.
+    if (classes == 1) {
         const float nx = fabsf(tri_exact[3 * (size_t)i].w), ny = fabsf(tri_exact[3 * (size_t)i + 1].w), nz = fabsf(tri_exact[3 * (size_t)i + 2].w);
         const uint32_t cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
         code = (code >> 2) | (cls << 28);
+    } else if (classes == 2) {
+        const uint32_t cls = bvh_normal_class(mk(tri_exact[3 * (size_t)i].w, tri_exact[3 * (size_t)i + 1].w, tri_exact[3 * (size_t)i + 2].w), e1, e2, big_thr);
+        if (cls) code = (1u << 30) | ((cls - 1u) << 22) | (code3 >> 8);        // (all three axes interleaved: seven bits each are left)
     }
     keys[i] = ((unsigned long long)code << 32) | i;
 }
@@ -259,7 +283,8 @@ __global__ __launch_bounds__(1024) void k_bvh_refit_top(uint32_t n, const uint32
     __shared__ uint32_t pending;
     if (n < 2) return;
     const uint32_t n_inner = n - 1u, count = *top_count;
-    for (;;) {
+    // (every round completes at least one listed node of a well-formed tree; the bound ends the loop for any other input)
+    for (uint32_t round = 0; round <= count; round++) {
         if (threadIdx.x == 0) pending = 0u;
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < count; j += blockDim.x) {
@@ -328,13 +353,16 @@ __global__ void k_bvh_emit(uint32_t n, const uint32_t *__restrict__ child, const
     uint32_t slot[4] = {child[2 * i], child[2 * i + 1], 0u, 0u};
     int ns = 2;
     for (int round = 0; round < 2; round++) {
-        int pick = -1; float best_area = -1.0f;
+        int pick = -1; float best_area = -1.0f; bool best_mixed = false;
         for (int k = 0; k < ns; k++) {
             if (bvh_ref_of(slot[k], n, range) & BVH_LEAF) continue;
             float4 lo = box_lo[slot[k]], hi = box_hi[slot[k]];
             float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
             float area = dx * dy + dy * dz + dz * dx;
-            if (area > best_area) { best_area = area; pick = k; }
+            // a child without a normal cone (it mixes orientation classes) is opened before any other: as a node of its own
+            // it would take the loose enlargement for all its slots, and every ray that reaches it would enter them all
+            const bool mixed = bvh_cone(nrm_lo[slot[k]], nrm_hi[slot[k]]).w >= 3.0e38f;
+            if ((mixed && !best_mixed) || (mixed == best_mixed && area > best_area)) { best_area = area; pick = k; best_mixed = mixed; }
         }
         if (pick < 0) break;
         uint32_t c = slot[pick];

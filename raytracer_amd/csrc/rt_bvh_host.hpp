@@ -51,6 +51,22 @@ struct Box {
     }
 };
 
+// Orientation class of a triangle record, see bvh_normal_class in rt_bvh.hpp (the device build's leading code bits)
+inline uint32_t normal_class(const float *r, float big_thr) {
+    const float e1 = std::sqrt(r[4] * r[4] + r[5] * r[5] + r[6] * r[6]), e2 = std::sqrt(r[8] * r[8] + r[9] * r[9] + r[10] * r[10]);
+    if (!(e1 * e2 > big_thr)) return 0u;
+    float c[3] = {r[3], r[7], r[11]};
+    if (c[0] * 0.267f + c[1] * 0.535f + c[2] * 0.802f < 0.f) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
+    const float l1 = std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]);
+    if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0u;
+    float u = c[0] / l1, v = c[1] / l1;
+    if (c[2] < 0.f) { const float uu = (1.0f - std::fabs(v)) * (u < 0.f ? -1.0f : 1.0f), vv = (1.0f - std::fabs(u)) * (v < 0.f ? -1.0f : 1.0f); u = uu; v = vv; }
+    const uint32_t qu = (uint32_t)std::min(14.0f, std::max(0.0f, (u + 1.0f) * 7.0f + 0.5f)), qv = (uint32_t)std::min(14.0f, std::max(0.0f, (v + 1.0f) * 7.0f + 0.5f));
+    uint32_t bin = 0;
+    for (int k = 0; k < 4; k++) bin |= (((qu >> k) & 1u) << (2 * k)) | (((qv >> k) & 1u) << (2 * k + 1));
+    return 1u + bin;
+}
+
 struct Job { uint32_t a, b, parent; int side; };          // leaves [a, b), b - a >= 2; the inner node they become hangs on parent's side
 
 struct Builder {
@@ -80,10 +96,12 @@ struct Builder {
         // Orientation classes are parted first (they end up as subtrees under the root): a node's normal cone, which
         // decides whether a ray may use the tight enlargement of the boxes, is only as narrow as the normals below it
         {
-            uint32_t cmin = 3, cmax = 0;
+            uint32_t cmin = 0xffffffffu, cmax = 0;
             for (uint32_t k = a; k < b; k++) { cmin = std::min(cmin, prim[k].cls); cmax = std::max(cmax, prim[k].cls); }
             if (cmin != cmax) {
-                auto it = std::partition(prim.begin() + a, prim.begin() + b, [&](const Prim &t) { return t.cls == cmin; });
+                // halved by class number (neighbouring directions have neighbouring numbers), so the classes form a balanced tree
+                const uint32_t cut = cmin + (cmax - cmin) / 2;
+                auto it = std::partition(prim.begin() + a, prim.begin() + b, [&](const Prim &t) { return t.cls <= cut; });
                 return (uint32_t)(it - prim.begin());
             }
         }
@@ -211,12 +229,24 @@ struct Builder {
 // `rec`: 12 floats per triangle, {p.xyz, c.x}{e1.xyz, c.y}{e2.xyz, c.z} with c = cross(e2, e1) (the device's exact-test
 // records); n >= 2.
 // Coordinates are finite (a scene with others gets no hierarchy at all).
-inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int threads, HostTopology &out)
+inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int threads, HostTopology &out, int class_mode = 2)
 {
     using namespace sah_detail;
     Builder b;
     b.n = n; b.refit_block = refit_block; b.out = &out;
     b.prim.resize(n);
+    float big_thr = 3.0e38f;
+    if (class_mode == 2) {
+        // (the device build's rule: large from sqrt(|e1||e2|) = 16 / scene size on)
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) {
+            const float *r = rec + 12 * (size_t)i;
+            const float v0 = r[k], v1 = r[k] + r[4 + k], v2 = r[k] + r[8 + k];
+            lo[k] = std::min(lo[k], std::min(v0, std::min(v1, v2))); hi[k] = std::max(hi[k], std::max(v0, std::max(v1, v2)));
+        }
+        const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+        if (emax > 0.f) big_thr = 256.0f / (emax * emax);
+    }
     for (uint32_t i = 0; i < n; i++) {
         const float *r = rec + 12 * (size_t)i;
         for (int k = 0; k < 3; k++) {
@@ -226,7 +256,9 @@ inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int
         b.prim[i].box.v[3] = 0.f; b.prim[i].box.v[7] = 0.f;
         b.prim[i].tri = i;
         const float nx = std::fabs(r[3]), ny = std::fabs(r[7]), nz = std::fabs(r[11]);        // cross(e2, e1), as the device's keys read it
-        b.prim[i].cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
+        if (class_mode == 0) b.prim[i].cls = 0u;
+        else if (class_mode == 1) b.prim[i].cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
+        else b.prim[i].cls = normal_class(r, big_thr);
     }
     out.child.assign(2 * (size_t)(n - 1), 0u); out.range.assign(2 * (size_t)(n - 1), 0u);
     out.parent.assign(2 * (size_t)n - 1, 0xffffffffu); out.top_list.clear();

@@ -346,9 +346,10 @@ def scene_soup(seed=9, n_tri=1500, extent=10.0) -> SceneSpec:
                      {"ambientColor": [0.05, 0.05, 0.05], "horizonColor": [0.2, 0.3, 0.4], "ambientFactor": 0.0})
 
 
-def scene_city(seed=12, cells=96, n_boxes=1500) -> SceneSpec:
+def scene_city(seed=12, cells=96, n_boxes=1500, yaw=False) -> SceneSpec:
     """Not a benchmark config: a ground grid with boxes of random size standing on it (walls, roofs and ground mix their
-    orientations in every neighbourhood, as a modelled scene does and the terrains of configs 2-5 do not), 2 lamps."""
+    orientations in every neighbourhood, as a modelled scene does and the terrains of configs 2-5 do not), 2 lamps.
+    `yaw`: the boxes are turned by random angles, so the walls' normals fill the horizontal directions."""
     rng = np.random.default_rng(seed)
     gv, gf, _ = grid_mesh(cells, cells, -24, 24, -40, 8)
     mats = [material((0.6, 0.6, 0.55), kd=0.8, ks=0.2, hard=20, kr=0.1), material((0.7, 0.5, 0.3), kd=0.9, ks=0.4, hard=40)]
@@ -357,6 +358,12 @@ def scene_city(seed=12, cells=96, n_boxes=1500) -> SceneSpec:
         x, z = rng.uniform(-23, 22), rng.uniform(-39, 7)
         w, d, hgt = rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.3, 3.0)
         bv, bf = box_mesh((x, 0, z), (x + w, hgt, z + d))
+        if yaw:                                     # every box turned about its own vertical axis
+            a = rng.uniform(0, np.pi)
+            c, sn = np.float32(np.cos(a)), np.float32(np.sin(a))
+            cx, cz = np.float32(x + 0.5 * w), np.float32(z + 0.5 * d)
+            px, pz = bv[:, 0] - cx, bv[:, 2] - cz
+            bv = np.stack([cx + c * px - sn * pz, bv[:, 1], cz + sn * px + c * pz], axis=-1).astype(np.float32)
         meshes.append((bv, bf, None, 1))
     V, F, UV, HAS, M = _merge(meshes)
     T, pos = camera((0, 9, 16), pitch_deg=-22)
@@ -378,6 +385,7 @@ def small_variant(name: str) -> SceneSpec:
         "ties": scene_ties,
         "soup": scene_soup,
         "city": lambda: scene_city(cells=16, n_boxes=40),
+        "city_yaw": lambda: scene_city(cells=16, n_boxes=40, yaw=True),
     }[name]()
 
 

@@ -5,7 +5,7 @@
 //   * an inner node's range is the concatenation of its children's ranges (left first)
 //   * top_list holds exactly the inner nodes whose range crosses a block boundary
 //   * the tree does not depend on the number of threads
-//   * triangles of one orientation class (axis closest to the normal) are contiguous in the leaf order
+//   * triangles of one orientation class (cell of the normal, large triangles only) are contiguous in the leaf order
 // usage: bvh_host_check [n_for_timing]   -> prints "ok" and, with an argument, the build time of a grid of that size
 #include "rt_bvh_host.hpp"
 #include <chrono>
@@ -33,16 +33,20 @@ static void check(uint32_t n, const std::vector<float> &rec_in, uint32_t block, 
 {
     const std::vector<float> rec = with_normals(n, rec_in);
     rt::sah_topology(n, rec.data(), block, threads, T);
-    // orientation classes are parted before anything else: along the leaf order the class changes at most twice
+    // orientation classes are parted before anything else: every class is one run of the leaf order
     {
-        int changes = 0; uint32_t last = 9;
-        for (uint32_t k = 0; k < n; k++) {
-            const float *t = &rec[12 * (size_t)(T.keys[k] & 0xffffffffu)];
-            const float nx = std::fabs(t[3]), ny = std::fabs(t[7]), nz = std::fabs(t[11]);
-            const uint32_t cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
-            if (cls != last) { changes += last != 9; last = cls; }
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (uint32_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) {
+            const float *r = &rec[12 * (size_t)i];
+            for (float v : {r[k], r[k] + r[4 + k], r[k] + r[8 + k]}) { lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); }
         }
-        CHECK(changes <= 2);
+        const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+        const float thr = emax > 0.f ? 256.0f / (emax * emax) : 3.0e38f;
+        std::set<uint32_t> seen; uint32_t last = 0xffffffffu;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t cls = rt::sah_detail::normal_class(&rec[12 * (size_t)(T.keys[k] & 0xffffffffu)], thr);
+            if (cls != last) { CHECK(!seen.count(cls)); seen.insert(cls); last = cls; }
+        }
     }
     CHECK(T.keys.size() == n && T.child.size() == 2 * (size_t)(n - 1) && T.range.size() == 2 * (size_t)(n - 1) && T.parent.size() == 2 * (size_t)n - 1);
     std::vector<char> seen(n, 0);

@@ -74,7 +74,7 @@ def soup():
 
 @pytest.mark.parametrize("algo", ["bvh", "scan"])
 @pytest.mark.parametrize("mode", [CPU, CL])
-@pytest.mark.parametrize("name", ["soup", "c2", "c5", "ties", "city"])
+@pytest.mark.parametrize("name", ["soup", "c2", "c5", "ties", "city", "city_yaw"])
 def test_adversarial_rays_match_oracle(soup, name, mode, algo):
     fs, ex, orc = soup(name)
     ex.set_algorithm(algo)

@@ -26,7 +26,7 @@ def _answers(ex, rays, w, h, depth):
     return out, fr
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5", "soup", "ties", "glass", "city"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5", "soup", "ties", "glass", "city", "city_yaw"])
 def test_optimized_hierarchy_gives_the_same_bits_and_the_oracles(name):
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
@@ -115,16 +115,18 @@ def test_random_soups_optimized_equals_scan(seed, n_tri, extent):
             assert np.array_equal(a, b), f"result {k}: {np.count_nonzero(a != b)} entries differ"
 
 
-def test_orientation_classes_keep_mixed_scenes_culled():
+@pytest.mark.parametrize("yaw", [False, True])
+def test_orientation_classes_keep_mixed_scenes_culled(yaw):
     """Boxes on a ground grid: walls, roofs and ground in every neighbourhood.  A subtree that mixes them has no normal cone,
     its boxes take the loose enlargement and nothing is culled (without the classes: 1000 and more node visits per ray,
     millions of stack overflows), so both builds part the orientation classes under the root.  The frame must be the
     oracle's on a grid of blocks, identical for both builds and for the build without classes, with few node visits and no
-    stack overflow."""
+    stack overflow.  `yaw`: the boxes stand at random angles, so the walls' normals fill the horizontal directions (normal
+    cells of the large triangles instead of three axis classes; culled less well, see the bounds below)."""
     import os
     from raytracer_amd.executor import HipExecutor
     from oracle.binding import Oracle
-    fs = scenegen.scene_city(cells=48, n_boxes=400).to_flat()
+    fs = scenegen.scene_city(cells=48, n_boxes=400, yaw=yaw).to_flat()
     W, H, depth = 320, 200, 2
     with HipExecutor(fs, device=0) as ex:
         a = ex.render(W, H, mode=CPU, max_depth=depth, tone=False)
@@ -141,8 +143,8 @@ def test_orientation_classes_keep_mixed_scenes_culled():
     for f in (a, b):
         st = f["stats"]
         assert st.bvh_stack_overflows == 0
-        assert sum(st.bvh_nodes) < 150 * st.rays, "the hierarchy does not cull"
-    assert sum(c["stats"].bvh_nodes) > 3 * sum(a["stats"].bvh_nodes)
+        assert sum(st.bvh_nodes) < (600 if yaw else 150) * st.rays, "the hierarchy does not cull"
+    assert sum(c["stats"].bvh_nodes) > (1.5 if yaw else 3) * sum(a["stats"].bvh_nodes)
     orc = Oracle(fs)
     for (x, y) in ((0, 0), (152, 96), (312, 192), (96, 40), (224, 152)):
         ref = orc.render_region(W, H, x, y, 8, 8, mode=CPU, max_depth=depth, tone=0, n_threads=1)

@@ -8,15 +8,16 @@ from raytracer_amd import scenegen
 from raytracer_amd.executor import HipExecutor
 
 n_boxes = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-fs = scenegen.scene_city(n_boxes=n_boxes).to_flat()
+yaw = len(sys.argv) > 2 and sys.argv[2] == "yaw"
+fs = scenegen.scene_city(n_boxes=n_boxes, yaw=yaw).to_flat()
 W, H, depth = 1280, 720, 2
 ref = None
-for how in ("device build without orientation classes", "device build", "hipexec_optimize"):
-    os.environ.pop("HIPEXEC_CLASS_BITS", None)
-    if "without" in how:
-        os.environ["HIPEXEC_CLASS_BITS"] = "0"
+for how, bits, opt in (("device build, no orientation classes", "0", False), ("device build, three axis classes", "1", False),
+                       ("device build, normal cells for large triangles", "2", False), ("hipexec_optimize, three axis classes", "1", True),
+                       ("hipexec_optimize, normal cells for large triangles", "2", True)):
+    os.environ["HIPEXEC_CLASS_BITS"] = bits
     with HipExecutor(fs, device=0) as ex:
-        if how == "hipexec_optimize":
+        if opt:
             ms = ex.optimize()
         for _ in range(2):
             fr = ex.render(W, H, max_depth=depth, tone=False, time_kernels=False)
