@@ -105,8 +105,13 @@ DEV uint32_t morton_spread2(uint32_t v) {       // 10 bits -> every second bit
 // `classes`: leading bits name the orientation class (the code loses as many of its last bits), see below
 // Orientation class of a triangle for the leading code bits: 0 for a triangle too small for the loose enlargement of the
 // boxes to matter (|e1||e2| <= big_thr), else 1 + the cell of its unit normal (one hemisphere, as the cones take it) in a
-// 15 x 15 octahedral map, the cell's two indices bit-interleaved so that neighbouring directions share leading bits; the axis
+// 63 x 63 octahedral map, the cell's two indices bit-interleaved so that neighbouring directions share leading bits; the axis
 // directions fall in the middle of cells.  (rt_bvh_host.hpp has the same function for the host build.)
+#ifndef RT_BVH_CELL_BITS
+#define RT_BVH_CELL_BITS 6
+#endif
+constexpr int BVH_CELL_BITS = RT_BVH_CELL_BITS;      // bits per index of the normal map: 63 x 63 cells of about 3 degrees (4: 15 x 15, 5: 31 x 31;
+                                                     // boxes at random angles: 68 / 47 / 37 ms per frame with 4 / 5 / 6)
 DEV uint32_t bvh_normal_class(f3 c, f3 e1, f3 e2, float big_thr) {
     const float ee = sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2));
     if (!(ee > big_thr)) return 0u;
@@ -115,9 +120,10 @@ DEV uint32_t bvh_normal_class(f3 c, f3 e1, f3 e2, float big_thr) {
     if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0u;
     float u = c.x / l1, v = c.y / l1;
     if (c.z < 0.f) { const float uu = (1.0f - fabsf(v)) * (u < 0.f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.f ? -1.0f : 1.0f); u = uu; v = vv; }
-    const uint32_t qu = (uint32_t)fminf(14.0f, fmaxf(0.0f, (u + 1.0f) * 7.0f + 0.5f)), qv = (uint32_t)fminf(14.0f, fmaxf(0.0f, (v + 1.0f) * 7.0f + 0.5f));
+    const float half = (float)((1 << BVH_CELL_BITS) / 2 - 1);      // cells per half axis
+    const uint32_t qu = (uint32_t)fminf(2.0f * half, fmaxf(0.0f, (u + 1.0f) * half + 0.5f)), qv = (uint32_t)fminf(2.0f * half, fmaxf(0.0f, (v + 1.0f) * half + 0.5f));
     uint32_t bin = 0;
-    for (int b = 0; b < 4; b++) bin |= (((qu >> b) & 1u) << (2 * b)) | (((qv >> b) & 1u) << (2 * b + 1));
+    for (int b = 0; b < BVH_CELL_BITS; b++) bin |= (((qu >> b) & 1u) << (2 * b)) | (((qv >> b) & 1u) << (2 * b + 1));
     return 1u + bin;
 }
 
@@ -152,14 +158,14 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
     // 1500 boxes on a ground grid took 288 ms per 720p frame, 11.7 ms with the classes apart; C1 (a box on a plane) 0.212 ->
     // 0.110 ms; the terrains, whose triangles are small, are unchanged.  classes == 1: the axis the normal is closest to
     // (two bits); classes == 2, the default: for large triangles the cell of the normal in an octahedral map (walls that
-    // stand at any angle: 150 -> 68 ms for the same boxes turned by random angles), small triangles stay together.
+    // stand at any angle: 150 -> 37 ms for the same boxes turned by random angles), small triangles stay together.
     if (classes == 1) {
         const float nx = fabsf(tri_exact[3 * (size_t)i].w), ny = fabsf(tri_exact[3 * (size_t)i + 1].w), nz = fabsf(tri_exact[3 * (size_t)i + 2].w);
         const uint32_t cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
         code = (code >> 2) | (cls << 28);
     } else if (classes == 2) {
         const uint32_t cls = bvh_normal_class(mk(tri_exact[3 * (size_t)i].w, tri_exact[3 * (size_t)i + 1].w, tri_exact[3 * (size_t)i + 2].w), e1, e2, big_thr);
-        if (cls) code = (1u << 30) | ((cls - 1u) << 22) | (code3 >> 8);        // (all three axes interleaved: seven bits each are left)
+        if (cls) code = (1u << 30) | ((cls - 1u) << (30 - 2 * BVH_CELL_BITS)) | (code3 >> (2 * BVH_CELL_BITS));        // (all three axes interleaved)
     }
     keys[i] = ((unsigned long long)code << 32) | i;
 }

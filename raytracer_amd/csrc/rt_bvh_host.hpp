@@ -52,6 +52,10 @@ struct Box {
 };
 
 // Orientation class of a triangle record, see bvh_normal_class in rt_bvh.hpp (the device build's leading code bits)
+#ifndef RT_BVH_CELL_BITS
+#define RT_BVH_CELL_BITS 6
+#endif
+constexpr int HOST_CELL_BITS = RT_BVH_CELL_BITS;
 inline uint32_t normal_class(const float *r, float big_thr) {
     const float e1 = std::sqrt(r[4] * r[4] + r[5] * r[5] + r[6] * r[6]), e2 = std::sqrt(r[8] * r[8] + r[9] * r[9] + r[10] * r[10]);
     if (!(e1 * e2 > big_thr)) return 0u;
@@ -61,9 +65,10 @@ inline uint32_t normal_class(const float *r, float big_thr) {
     if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0u;
     float u = c[0] / l1, v = c[1] / l1;
     if (c[2] < 0.f) { const float uu = (1.0f - std::fabs(v)) * (u < 0.f ? -1.0f : 1.0f), vv = (1.0f - std::fabs(u)) * (v < 0.f ? -1.0f : 1.0f); u = uu; v = vv; }
-    const uint32_t qu = (uint32_t)std::min(14.0f, std::max(0.0f, (u + 1.0f) * 7.0f + 0.5f)), qv = (uint32_t)std::min(14.0f, std::max(0.0f, (v + 1.0f) * 7.0f + 0.5f));
+    const float half = (float)((1 << HOST_CELL_BITS) / 2 - 1);
+    const uint32_t qu = (uint32_t)std::min(2.0f * half, std::max(0.0f, (u + 1.0f) * half + 0.5f)), qv = (uint32_t)std::min(2.0f * half, std::max(0.0f, (v + 1.0f) * half + 0.5f));
     uint32_t bin = 0;
-    for (int k = 0; k < 4; k++) bin |= (((qu >> k) & 1u) << (2 * k)) | (((qv >> k) & 1u) << (2 * k + 1));
+    for (int k = 0; k < HOST_CELL_BITS; k++) bin |= (((qu >> k) & 1u) << (2 * k)) | (((qv >> k) & 1u) << (2 * k + 1));
     return 1u + bin;
 }
 
