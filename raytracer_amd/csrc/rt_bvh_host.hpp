@@ -2,8 +2,9 @@
 //
 // The device builds its hierarchy in under a millisecond from Morton order (rt_bvh.hpp), which is what an executor
 // that lives for one frame needs (ray_tracer_cl.cpp:14).  A scene that is kept can pay for a better tree once: a top-down
-// binned surface-area build groups the triangles by what their boxes cost, not by a fixed grid (frames of the scenes
-// measured: C1 0.213 -> 0.147 ms; the regular terrains C2-C5 within 1 %).  Only the TOPOLOGY is made here: the
+// binned surface-area build groups the triangles by what their boxes cost, not by a fixed grid (5-10 % of a frame on
+// scenes of boxes and walls; the device build, which took over what this one taught - box centres, tight grid, orientation
+// classes - is level with it on the regular terrains).  Only the TOPOLOGY is made here: the
 // order of the triangles and the binary tree over that order, in the numbering of k_bvh_split, so that the device's
 // refit and emit kernels, the 4-wide records and the traversal are the same for both builds.  The hierarchy decides
 // which exact tests run, never their outcome, so frames are bit-identical with either tree.
