@@ -75,6 +75,11 @@ WORKLOADS = {
     "c5": ("scene_c5", {}, 3840, 2160, 0, "C5: 20k tris + 16 spheres, 16 lamps, 3840x2160, depth 0"),
     "soup": ("scene_soup", {"seed": 105, "n_tri": 40000, "extent": 50.0}, 640, 480, 3,
              "soup: 40000 random triangles up to scene size (a few rays per frame outgrow the traversal stack), 640x480, depth 3"),
+    "city": ("scene_city", {}, 1920, 1080, 2,
+             "city (not a BASELINE config): 1500 boxes on a 96 x 96 ground grid, 36432 triangles, 2 lamps: walls, roofs and ground mix "
+             "their orientations in every neighbourhood; 1920x1080, 4 spp, depth 2"),
+    "city_yaw": ("scene_city", {"yaw": True}, 1920, 1080, 2,
+                 "city_yaw (not a BASELINE config): the city's boxes turned by random angles (large triangles in every orientation), 1920x1080, depth 2"),
     "tiny": ("scene_c2", {"cells": 24, "tex_size": 64}, 256, 144, 3, "tiny: 1152-tri C2 variant at 256x144 (functional check only)"),
 }
 
