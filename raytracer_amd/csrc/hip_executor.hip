@@ -338,6 +338,7 @@ struct SceneShare {
     std::vector<float> lamp_pos_host;         // lamp positions, for the lamp records of the scans
     bool scan_shared = false;                 // pair_gen / pair_lamp / chunk_box exist
     bool optimized = false;                   // the hierarchy has the surface-area topology (hipexec_optimize)
+    uint32_t popular[sah_detail::CELL_WORDS] = {};   // normal cells that hold a fifth of the triangle area (orientation classes)
     const PairGen *pair_gen = nullptr; const PairCam *pair_lamp = nullptr; const float4 *chunk_box = nullptr;
     // remembered queue sizes (newest last, at most 64), common to the executors of the scene and their lanes: with
     // several frames in flight each executor sizes its next frame from the newest frame any of them has collected
@@ -583,10 +584,13 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             const int classes = cb ? std::max(0, std::min(2, atoi(cb))) : 2;
             // a triangle counts as large from sqrt(|e1||e2|) = 16 / (scene size) on: from there its loose enlargement, 3e-2 |e1||e2|
             // times the distance, exceeds its own size at scene-size distances
-            const float big_thr = emax > 0.f ? 256.0f / (emax * emax) : 3.0e38f;
+            uint32_t *d_popular = nullptr;
+            if (classes == 2) CHK(upload<uint32_t>(h, h->share->popular, sah_detail::CELL_WORDS, &d_popular));
+            float big_thr = emax > 0.f ? 256.0f / (emax * emax) : 3.0e38f;
+            if (const char *e = knob("HIPEXEC_BIG_SCALE")) big_thr *= (float)atof(e);          // experiment
             int minor = h->morton_minor;
             if (const char *e = knob("HIPEXEC_MORTON_MINOR")) minor = std::max(-1, std::min(2, atoi(e)));
-            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, classes, big_thr, keys_a);
+            hipLaunchKernelGGL(k_bvh_keys, grid, blk, 0, h->stream, n, tri_exact, flo, inv, minor, classes, big_thr, d_popular, keys_a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp_bytes, keys_a, keys_b, (int)n, 0, 63, h->stream));
         } else {
@@ -598,7 +602,7 @@ int build_bvh(hipexec *h, const float4 *tri_exact, const double *lo, const doubl
             HostTopology T;
             int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
             if (const char *e = knob("HIPEXEC_BUILD_THREADS")) threads = std::max(1, atoi(e));
-            try { sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T, knob("HIPEXEC_CLASS_BITS") ? std::max(0, std::min(2, atoi(knob("HIPEXEC_CLASS_BITS")))) : 2); }
+            try { sah_topology(n, &rec[0].x, REFIT_BLOCK, threads, T, knob("HIPEXEC_CLASS_BITS") ? std::max(0, std::min(2, atoi(knob("HIPEXEC_CLASS_BITS")))) : 2, h->share->popular); }
             catch (const std::exception &e) { return fail(HIPEXEC_E_NOMEM, "surface-area build on the host: %s", e.what()); }     // nothing on the device has been touched yet
             const uint32_t tc = (uint32_t)T.top_list.size();
             HIPCHK(hipMemcpyAsync(keys_b, T.keys.data(), 8 * (size_t)n, hipMemcpyHostToDevice, h->stream));
@@ -759,6 +763,7 @@ int build_scene(hipexec *h, const hipexec_scene_desc *s)
         for (int k = 0; k < 3; k++)
             if (cnt && ext[k] < 0.25 * emax && sum[k] > 0.8 * (double)cnt && (h->morton_minor < 0 || ext[k] < ext[h->morton_minor])) h->morton_minor = k;
     }
+    if (all_finite && s->n_tri) sah_detail::popular_cells(s->n_tri, s->tri_e1, s->tri_e2, 3, h->share->popular);
     CHK(build_bvh(h, ex, tri_lo, tri_hi, all_finite));
     STAGE("hierarchy build");
     // what the build does not read goes up on the side stream while the build's kernels run

@@ -104,7 +104,7 @@ DEV uint32_t morton_spread2(uint32_t v) {       // 10 bits -> every second bit
 // `minor` = -1: the three axes interleaved; 0..2: that axis' ten bits come last, the other two are interleaved above them;
 // `classes`: leading bits name the orientation class (the code loses as many of its last bits), see below
 // Orientation class of a triangle for the leading code bits: 0 for a triangle too small for the loose enlargement of the
-// boxes to matter (|e1||e2| <= big_thr), else 1 + the cell of its unit normal (one hemisphere, as the cones take it) in a
+// boxes to matter (|e1||e2| <= big_thr) and not part of a finely tiled plane, else 1 + the cell of its unit normal (one hemisphere, as the cones take it) in a
 // 63 x 63 octahedral map, the cell's two indices bit-interleaved so that neighbouring directions share leading bits; the axis
 // directions fall in the middle of cells.  (rt_bvh_host.hpp has the same function for the host build.)
 #ifndef RT_BVH_CELL_BITS
@@ -112,9 +112,7 @@ DEV uint32_t morton_spread2(uint32_t v) {       // 10 bits -> every second bit
 #endif
 constexpr int BVH_CELL_BITS = RT_BVH_CELL_BITS;      // bits per index of the normal map: 63 x 63 cells of about 3 degrees (4: 15 x 15, 5: 31 x 31;
                                                      // boxes at random angles: 68 / 47 / 37 ms per frame with 4 / 5 / 6)
-DEV uint32_t bvh_normal_class(f3 c, f3 e1, f3 e2, float big_thr) {
-    const float ee = sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2));
-    if (!(ee > big_thr)) return 0u;
+DEV uint32_t bvh_normal_class(f3 c, f3 e1, f3 e2, float big_thr, const uint32_t *__restrict__ popular) {
     if (c.x * 0.267f + c.y * 0.535f + c.z * 0.802f < 0.f) c = -c;
     const float l1 = fabsf(c.x) + fabsf(c.y) + fabsf(c.z);
     if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0u;
@@ -124,11 +122,14 @@ DEV uint32_t bvh_normal_class(f3 c, f3 e1, f3 e2, float big_thr) {
     const uint32_t qu = (uint32_t)fminf(2.0f * half, fmaxf(0.0f, (u + 1.0f) * half + 0.5f)), qv = (uint32_t)fminf(2.0f * half, fmaxf(0.0f, (v + 1.0f) * half + 0.5f));
     uint32_t bin = 0;
     for (int b = 0; b < BVH_CELL_BITS; b++) bin |= (((qu >> b) & 1u) << (2 * b)) | (((qv >> b) & 1u) << (2 * b + 1));
+    // large, or in a cell that holds a fifth of the scene's triangle area (a finely tiled plane: rt_bvh_host.hpp, popular_cells)
+    const float ee = sqrtf(dot(e1, e1)) * sqrtf(dot(e2, e2));
+    if (!(ee > big_thr) && !(popular && ((popular[bin >> 5] >> (bin & 31u)) & 1u))) return 0u;
     return 1u + bin;
 }
 
 __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 lo, f3 inv_ext, int minor, int classes, float big_thr,
-                           unsigned long long *__restrict__ keys)
+                           const uint32_t *__restrict__ popular, unsigned long long *__restrict__ keys)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -164,7 +165,7 @@ __global__ void k_bvh_keys(uint32_t n, const float4 *__restrict__ tri_exact, f3 
         const uint32_t cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
         code = (code >> 2) | (cls << 28);
     } else if (classes == 2) {
-        const uint32_t cls = bvh_normal_class(mk(tri_exact[3 * (size_t)i].w, tri_exact[3 * (size_t)i + 1].w, tri_exact[3 * (size_t)i + 2].w), e1, e2, big_thr);
+        const uint32_t cls = bvh_normal_class(mk(tri_exact[3 * (size_t)i].w, tri_exact[3 * (size_t)i + 1].w, tri_exact[3 * (size_t)i + 2].w), e1, e2, big_thr, popular);
         if (cls) code = (1u << 30) | ((cls - 1u) << (30 - 2 * BVH_CELL_BITS)) | (code3 >> (2 * BVH_CELL_BITS));        // (all three axes interleaved)
     }
     keys[i] = ((unsigned long long)code << 32) | i;

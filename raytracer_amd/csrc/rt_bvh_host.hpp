@@ -57,20 +57,48 @@ struct Box {
 #define RT_BVH_CELL_BITS 6
 #endif
 constexpr int HOST_CELL_BITS = RT_BVH_CELL_BITS;
-inline uint32_t normal_class(const float *r, float big_thr) {
-    const float e1 = std::sqrt(r[4] * r[4] + r[5] * r[5] + r[6] * r[6]), e2 = std::sqrt(r[8] * r[8] + r[9] * r[9] + r[10] * r[10]);
-    if (!(e1 * e2 > big_thr)) return 0u;
-    float c[3] = {r[3], r[7], r[11]};
-    if (c[0] * 0.267f + c[1] * 0.535f + c[2] * 0.802f < 0.f) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
-    const float l1 = std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]);
-    if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0u;
-    float u = c[0] / l1, v = c[1] / l1;
-    if (c[2] < 0.f) { const float uu = (1.0f - std::fabs(v)) * (u < 0.f ? -1.0f : 1.0f), vv = (1.0f - std::fabs(u)) * (v < 0.f ? -1.0f : 1.0f); u = uu; v = vv; }
+constexpr uint32_t CELL_WORDS = (1u << (2 * HOST_CELL_BITS)) / 32u;       // words of a bit mask over the cells
+
+// Cell of a normal direction (any length, either sign) in the octahedral map, 0xffffffff for a zero or non-finite vector
+inline uint32_t normal_cell(float cx, float cy, float cz) {
+    if (cx * 0.267f + cy * 0.535f + cz * 0.802f < 0.f) { cx = -cx; cy = -cy; cz = -cz; }
+    const float l1 = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);
+    if (!(l1 > 0.f) || !(l1 < 3.0e38f)) return 0xffffffffu;
+    float u = cx / l1, v = cy / l1;
+    if (cz < 0.f) { const float uu = (1.0f - std::fabs(v)) * (u < 0.f ? -1.0f : 1.0f), vv = (1.0f - std::fabs(u)) * (v < 0.f ? -1.0f : 1.0f); u = uu; v = vv; }
     const float half = (float)((1 << HOST_CELL_BITS) / 2 - 1);
     const uint32_t qu = (uint32_t)std::min(2.0f * half, std::max(0.0f, (u + 1.0f) * half + 0.5f)), qv = (uint32_t)std::min(2.0f * half, std::max(0.0f, (v + 1.0f) * half + 0.5f));
     uint32_t bin = 0;
     for (int k = 0; k < HOST_CELL_BITS; k++) bin |= (((qu >> k) & 1u) << (2 * k)) | (((qv >> k) & 1u) << (2 * k + 1));
-    return 1u + bin;
+    return bin;
+}
+
+// Cells that hold at least a fifth of the scene's triangle area: planes tiled finely (a ground of small quads, the walls
+// of many aligned boxes).  Their triangles are parted by orientation whatever their size; a terrain, whose normals spread
+// over many cells, has none (at a twentieth the gentle terrain of C4 had, and lost 25 %).  e1 / e2: [n][stride] floats, the first three of each the edge.
+inline void popular_cells(size_t n, const float *e1, const float *e2, size_t stride, uint32_t *mask /* [CELL_WORDS] */) {
+    std::vector<double> area((size_t)CELL_WORDS * 32u, 0.0);
+    double total = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        const float *a = e1 + i * stride, *b = e2 + i * stride;
+        const float cx = b[1] * a[2] - b[2] * a[1], cy = b[2] * a[0] - b[0] * a[2], cz = b[0] * a[1] - b[1] * a[0];      // cross(e2, e1)
+        const uint32_t cell = normal_cell(cx, cy, cz);
+        if (cell == 0xffffffffu) continue;
+        const double w = std::sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
+        if (!(w < 1.0e300)) continue;
+        area[cell] += w; total += w;
+    }
+    for (uint32_t w = 0; w < CELL_WORDS; w++) mask[w] = 0u;
+    for (uint32_t c = 0; c < CELL_WORDS * 32u; c++) if (total > 0.0 && area[c] >= 0.2 * total) mask[c >> 5] |= 1u << (c & 31u);
+}
+
+// Orientation class of a triangle record, see bvh_normal_class in rt_bvh.hpp (the device build's leading code bits)
+inline uint32_t normal_class(const float *r, float big_thr, const uint32_t *popular) {
+    const uint32_t cell = normal_cell(r[3], r[7], r[11]);
+    if (cell == 0xffffffffu) return 0u;
+    const float e1 = std::sqrt(r[4] * r[4] + r[5] * r[5] + r[6] * r[6]), e2 = std::sqrt(r[8] * r[8] + r[9] * r[9] + r[10] * r[10]);
+    if (!(e1 * e2 > big_thr) && !(popular && ((popular[cell >> 5] >> (cell & 31u)) & 1u))) return 0u;
+    return 1u + cell;
 }
 
 struct Job { uint32_t a, b, parent; int side; };          // leaves [a, b), b - a >= 2; the inner node they become hangs on parent's side
@@ -235,13 +263,15 @@ struct Builder {
 // `rec`: 12 floats per triangle, {p.xyz, c.x}{e1.xyz, c.y}{e2.xyz, c.z} with c = cross(e2, e1) (the device's exact-test
 // records); n >= 2.
 // Coordinates are finite (a scene with others gets no hierarchy at all).
-inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int threads, HostTopology &out, int class_mode = 2)
+inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int threads, HostTopology &out, int class_mode = 2,
+                         const uint32_t *popular = nullptr)
 {
     using namespace sah_detail;
     Builder b;
     b.n = n; b.refit_block = refit_block; b.out = &out;
     b.prim.resize(n);
     float big_thr = 3.0e38f;
+    std::vector<uint32_t> own_mask;
     if (class_mode == 2) {
         // (the device build's rule: large from sqrt(|e1||e2|) = 16 / scene size on)
         float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -252,6 +282,7 @@ inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int
         }
         const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
         if (emax > 0.f) big_thr = 256.0f / (emax * emax);
+        if (!popular) { own_mask.resize(CELL_WORDS); popular_cells(n, rec + 4, rec + 8, 12, own_mask.data()); popular = own_mask.data(); }
     }
     for (uint32_t i = 0; i < n; i++) {
         const float *r = rec + 12 * (size_t)i;
@@ -264,7 +295,7 @@ inline void sah_topology(uint32_t n, const float *rec, uint32_t refit_block, int
         const float nx = std::fabs(r[3]), ny = std::fabs(r[7]), nz = std::fabs(r[11]);        // cross(e2, e1), as the device's keys read it
         if (class_mode == 0) b.prim[i].cls = 0u;
         else if (class_mode == 1) b.prim[i].cls = (nx >= ny && nx >= nz) ? 0u : (ny >= nz ? 1u : 2u);
-        else b.prim[i].cls = normal_class(r, big_thr);
+        else b.prim[i].cls = normal_class(r, big_thr, popular);
     }
     out.child.assign(2 * (size_t)(n - 1), 0u); out.range.assign(2 * (size_t)(n - 1), 0u);
     out.parent.assign(2 * (size_t)n - 1, 0xffffffffu); out.top_list.clear();

@@ -42,9 +42,11 @@ static void check(uint32_t n, const std::vector<float> &rec_in, uint32_t block, 
         }
         const float emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
         const float thr = emax > 0.f ? 256.0f / (emax * emax) : 3.0e38f;
+        std::vector<uint32_t> mask(rt::sah_detail::CELL_WORDS);
+        rt::sah_detail::popular_cells(n, rec.data() + 4, rec.data() + 8, 12, mask.data());
         std::set<uint32_t> seen; uint32_t last = 0xffffffffu;
         for (uint32_t k = 0; k < n; k++) {
-            const uint32_t cls = rt::sah_detail::normal_class(&rec[12 * (size_t)(T.keys[k] & 0xffffffffu)], thr);
+            const uint32_t cls = rt::sah_detail::normal_class(&rec[12 * (size_t)(T.keys[k] & 0xffffffffu)], thr, mask.data());
             if (cls != last) { CHECK(!seen.count(cls)); seen.insert(cls); last = cls; }
         }
     }
